@@ -1,0 +1,329 @@
+"""ctypes binding of libatlasfit.so (include/atlasfit.h).
+
+`AtlasFit` mirrors the objects the reference's loop drives (src/stage1_neural_atlas.py:112-231):
+two IMLP networks addressed through `state_dict()`-compatible dictionaries (keys `hidden.{i}.weight`,
+`hidden.{i}.bias`, implicit_neural_networks.py:37-52), `pre_train_mapping` (unwrap_utils.py:176-198) and the
+loop body.  torch is imported first so the library binds to torch's HIP runtime (one runtime per process).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NET_MAPPING1, NET_ATLAS, NET_MAPPING2, NET_ALPHA = 0, 1, 2, 3
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libatlasfit.so")
+_lib = None
+
+# symbols declared in include/atlasfit.h (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "af_create", "af_destroy", "af_last_error", "af_upload_video", "af_param_count", "af_set_params",
+    "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
+    "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
+    "af_set_timing", "af_get_timing", "af_step_work",
+]
+
+
+class AtlasFitError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("atlasfit error %d: %s" % (code, msg))
+        self.code = code
+
+
+class AfConfig(C.Structure):
+    _fields_ = [
+        ("resx", C.c_int32), ("resy", C.c_int32), ("number_of_frames", C.c_int32),
+        ("samples_batch", C.c_int32),
+        ("number_of_channels_mapping1", C.c_int32), ("number_of_layers_mapping1", C.c_int32),
+        ("number_of_channels_atlas", C.c_int32), ("number_of_layers_atlas", C.c_int32),
+        ("positional_encoding_num_atlas", C.c_int32),
+        ("use_positional_encoding_mapping1", C.c_int32),
+        ("derivative_amount", C.c_int32),
+        ("include_global_rigidity_loss", C.c_int32),
+        ("global_rigidity_derivative_amount_fg", C.c_int32),
+        ("stop_global_rigidity", C.c_int32),
+        ("use_gradient_loss", C.c_int32),
+        ("rgb_coeff", C.c_float), ("gradient_loss_coeff", C.c_float), ("rigidity_coeff", C.c_float),
+        ("optical_flow_coeff", C.c_float),
+        ("global_rigidity_coeff_fg", C.c_float),
+        ("uv_mapping_scale", C.c_float),
+        ("lr", C.c_float),
+        ("pretrain_batch", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+# the shipped hyper-parameters (reference src/config/config_flow_100.json)
+REFERENCE_CONFIG = {
+    "maximum_number_of_frames": 200, "iters_num": 10001, "samples_batch": 10000, "optical_flow_coeff": 500.0,
+    "evaluate_every": 10000, "derivative_amount": 1, "rgb_coeff": 5000, "rigidity_coeff": 1.0,
+    "uv_mapping_scale": 0.8, "pretrain_mapping1": True, "pretrain_mapping2": True,
+    "alpha_bootstrapping_factor": 2000.0, "alpha_flow_factor": 4900.0, "positional_encoding_num_alpha": 5,
+    "number_of_channels_atlas": 256, "number_of_layers_atlas": 8, "number_of_channels_alpha": 256,
+    "number_of_layers_alpha": 8, "stop_bootstrapping_iteration": 10000, "number_of_channels_mapping1": 256,
+    "number_of_layers_mapping1": 6, "number_of_channels_mapping2": 256, "number_of_layers_mapping2": 4,
+    "gradient_loss_coeff": 1000, "use_gradient_loss": True, "sparsity_coeff": 1000.0,
+    "positional_encoding_num_atlas": 10, "use_positional_encoding_mapping1": False,
+    "number_of_positional_encoding_mapping1": 4, "use_positional_encoding_mapping2": False,
+    "number_of_positional_encoding_mapping2": 2, "pretrain_iter_number": 100, "load_checkpoint": False,
+    "checkpoint_path": "", "include_global_rigidity_loss": True, "global_rigidity_derivative_amount_fg": 100,
+    "global_rigidity_derivative_amount_bg": 100, "global_rigidity_coeff_fg": 5.0, "global_rigidity_coeff_bg": 50.0,
+    "stop_global_rigidity": 5000,
+}
+
+
+def default_config(resx, resy, number_of_frames, config=None, **over):
+    """af_config from the reference's JSON config dict (keys as read at stage1_neural_atlas.py:28-90)."""
+    cfg = dict(REFERENCE_CONFIG)
+    if config:
+        cfg.update(config)
+    cfg.update(over)
+    c = AfConfig()
+    c.resx, c.resy, c.number_of_frames = int(resx), int(resy), int(number_of_frames)
+    c.samples_batch = int(cfg["samples_batch"])
+    c.number_of_channels_mapping1 = int(cfg["number_of_channels_mapping1"])
+    c.number_of_layers_mapping1 = int(cfg["number_of_layers_mapping1"])
+    c.number_of_channels_atlas = int(cfg["number_of_channels_atlas"])
+    c.number_of_layers_atlas = int(cfg["number_of_layers_atlas"])
+    c.positional_encoding_num_atlas = int(cfg["positional_encoding_num_atlas"])
+    c.use_positional_encoding_mapping1 = int(bool(cfg["use_positional_encoding_mapping1"]))
+    c.derivative_amount = int(cfg["derivative_amount"])
+    c.include_global_rigidity_loss = int(bool(cfg["include_global_rigidity_loss"]))
+    c.global_rigidity_derivative_amount_fg = int(cfg["global_rigidity_derivative_amount_fg"])
+    c.stop_global_rigidity = int(cfg["stop_global_rigidity"])
+    c.use_gradient_loss = int(bool(cfg["use_gradient_loss"]))
+    c.rgb_coeff = float(cfg["rgb_coeff"])
+    c.gradient_loss_coeff = float(cfg["gradient_loss_coeff"])
+    c.rigidity_coeff = float(cfg["rigidity_coeff"])
+    c.optical_flow_coeff = float(cfg["optical_flow_coeff"])
+    c.global_rigidity_coeff_fg = float(cfg["global_rigidity_coeff_fg"])
+    c.uv_mapping_scale = float(cfg["uv_mapping_scale"])
+    c.lr = float(cfg.get("lr", 1e-4))
+    c.pretrain_batch = int(cfg.get("pretrain_batch", 10000))
+    return c
+
+
+def load_library(path=None):
+    """dlopen libatlasfit.so.  Fails loudly if it has not been built (python build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must come first: share torch's HIP runtime)
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise AtlasFitError(-100, "libatlasfit.so not built: run `python %s`" % os.path.join(_HERE, "build.py"))
+    lib = C.CDLL(path)
+    vp, i32, i64, u64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t
+    fp = C.POINTER(C.c_float)
+    sig = {
+        "af_create": (i32, [C.POINTER(AfConfig), i32, C.POINTER(vp)]),
+        "af_destroy": (None, [vp]),
+        "af_last_error": (C.c_char_p, [vp]),
+        "af_upload_video": (i32, [vp, vp, vp, vp, vp, vp, vp, i32]),
+        "af_param_count": (sz, [vp, i32]),
+        "af_set_params": (i32, [vp, i32, vp, sz]),
+        "af_get_params": (i32, [vp, i32, vp, sz]),
+        "af_get_adam_state": (i32, [vp, i32, vp, vp, C.POINTER(i64)]),
+        "af_set_adam_state": (i32, [vp, i32, vp, vp, i64]),
+        "af_pretrain": (i32, [vp, i32, i32, vp, vp, u64, vp]),
+        "af_train_steps": (i32, [vp, i32, i32, vp, u64, vp]),
+        "af_render_frame": (i32, [vp, i32, vp, C.POINTER(C.c_double)]),
+        "af_psnr": (i32, [vp, C.POINTER(C.c_double), vp]),
+        "af_sync": (i32, [vp]),
+        "af_debug_forward": (i32, [vp, i32, vp, i32, vp]),
+        "af_set_debug": (i32, [vp, i32]),
+        "af_get_last_grads": (i32, [vp, i32, vp, sz]),
+        "af_set_timing": (i32, [vp, i32]),
+        "af_get_timing": (i32, [vp, vp, vp, i32]),
+        "af_step_work": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# layer shapes of the two IMLPs of the single-atlas path (stage1_neural_atlas.py:112-128)
+def imlp_shapes(net, pe_atlas=10):
+    if net == NET_MAPPING1:
+        dims = [(256, 3)] + [(256, 256)] * 4 + [(2, 256)]
+    elif net == NET_ATLAS:
+        e = 4 * pe_atlas
+        dims = [(256, e), (256, 256), (256, 256), (256, 256), (256, 256 + e), (256, 256), (256, 256), (3, 256 + e)]
+    else:
+        raise ValueError("net")
+    return dims
+
+
+def flatten_state_dict(sd, net):
+    """IMLP.state_dict() (torch tensors or arrays) -> flat fp32 vector in state_dict order."""
+    parts = []
+    for i, (o, k) in enumerate(imlp_shapes(net)):
+        w = np.asarray(sd["hidden.%d.weight" % i].detach().cpu().numpy() if hasattr(sd["hidden.%d.weight" % i], "detach") else sd["hidden.%d.weight" % i], dtype=np.float32)
+        b = np.asarray(sd["hidden.%d.bias" % i].detach().cpu().numpy() if hasattr(sd["hidden.%d.bias" % i], "detach") else sd["hidden.%d.bias" % i], dtype=np.float32)
+        assert w.shape == (o, k) and b.shape == (o,), (i, w.shape, b.shape)
+        parts += [w.reshape(-1), b]
+    return np.concatenate(parts)
+
+
+def unflatten_state_dict(flat, net):
+    out, off = {}, 0
+    for i, (o, k) in enumerate(imlp_shapes(net)):
+        out["hidden.%d.weight" % i] = flat[off:off + o * k].reshape(o, k).copy(); off += o * k
+        out["hidden.%d.bias" % i] = flat[off:off + o].copy(); off += o
+    assert off == flat.size
+    return out
+
+
+class AtlasFit:
+    """One video on one MI355X.  Mirrors the objects of stage1_neural_atlas.main()."""
+
+    LOSS_NAMES = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total", "valid_fwd", "valid_bwd")
+
+    def __init__(self, cfg, device=0):
+        self.lib = load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.af_create(C.byref(cfg), int(device), C.byref(h))
+        if rc != 0:
+            raise AtlasFitError(rc, self.lib.af_last_error(None).decode())
+        self.h = h
+        self.N = cfg.samples_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.af_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AtlasFitError(rc, self.lib.af_last_error(self.h).decode())
+
+    # ---- data (load_input_data_single outputs, unwrap_utils.py:105-163)
+    def upload_video(self, video_frames, optical_flows, optical_flows_reverse, optical_flows_mask,
+                     optical_flows_reverse_mask, mask_frames=None):
+        c = self.cfg
+        shp = (c.resy, c.resx, 3, c.number_of_frames)
+        if hasattr(video_frames, "is_cuda") and video_frames.is_cuda:      # torch tensors already in HBM
+            ts = [video_frames, optical_flows, optical_flows_reverse, optical_flows_mask, optical_flows_reverse_mask, mask_frames]
+            ts = [None if t is None else t.contiguous().float() for t in ts]
+            assert tuple(ts[0].shape) == shp, (tuple(ts[0].shape), shp)
+            import torch
+            torch.cuda.synchronize()
+            ptrs = [None if t is None else C.c_void_p(t.data_ptr()) for t in ts]
+            self._chk(self.lib.af_upload_video(self.h, *ptrs, 1))
+            return
+        arrs = [video_frames, optical_flows, optical_flows_reverse, optical_flows_mask, optical_flows_reverse_mask, mask_frames]
+        arrs = [None if a is None else _f32(a.numpy() if hasattr(a, "numpy") else a) for a in arrs]
+        assert arrs[0].shape == shp, (arrs[0].shape, shp)
+        assert arrs[1].size == c.resy * c.resx * 2 * c.number_of_frames
+        assert arrs[3].size == c.resy * c.resx * c.number_of_frames
+        self._chk(self.lib.af_upload_video(self.h, *[_ptr(a) for a in arrs], 0))
+
+    # ---- parameters
+    def param_count(self, net):
+        return int(self.lib.af_param_count(self.h, net))
+
+    def load_state_dict(self, net, sd):
+        flat = flatten_state_dict(sd, net)
+        self._chk(self.lib.af_set_params(self.h, net, _ptr(flat), flat.size))
+
+    def state_dict(self, net):
+        flat = np.empty(self.param_count(net), np.float32)
+        self._chk(self.lib.af_get_params(self.h, net, _ptr(flat), flat.size))
+        return unflatten_state_dict(flat, net)
+
+    def get_params_flat(self, net):
+        flat = np.empty(self.param_count(net), np.float32)
+        self._chk(self.lib.af_get_params(self.h, net, _ptr(flat), flat.size))
+        return flat
+
+    def adam_state(self, net):
+        n = self.param_count(net)
+        m, v, step = np.empty(n, np.float32), np.empty(n, np.float32), C.c_int64(0)
+        self._chk(self.lib.af_get_adam_state(self.h, net, _ptr(m), _ptr(v), C.byref(step)))
+        return m, v, int(step.value)
+
+    def set_adam_state(self, net, m, v, step):
+        m, v = _f32(m), _f32(v)
+        self._chk(self.lib.af_set_adam_state(self.h, net, _ptr(m), _ptr(v), int(step)))
+
+    # ---- pre_train_mapping (unwrap_utils.py:176-198)
+    def pre_train_mapping(self, pretrain_iters, ys=None, xs=None, seed=0, net=NET_MAPPING1, return_losses=False):
+        steps = pretrain_iters * self.cfg.number_of_frames
+        losses = np.zeros(steps, np.float32) if return_losses else None
+        if ys is not None:
+            ys = np.ascontiguousarray(ys, np.int64); xs = np.ascontiguousarray(xs, np.int64)
+            assert ys.size == steps * self.cfg.pretrain_batch == xs.size
+        self._chk(self.lib.af_pretrain(self.h, net, int(pretrain_iters), _ptr(ys), _ptr(xs), int(seed), _ptr(losses)))
+        return losses
+
+    # ---- the loop body (stage1_neural_atlas.py:151-231)
+    def train_steps(self, first_iter, n_iters, inds=None, seed=0, return_losses=True):
+        losses = np.zeros((n_iters, 8), np.float32) if return_losses else None
+        if inds is not None:
+            inds = np.ascontiguousarray(inds, np.int64)
+            assert inds.size == n_iters * self.N, (inds.shape, n_iters, self.N)
+        self._chk(self.lib.af_train_steps(self.h, int(first_iter), int(n_iters), _ptr(inds), int(seed), _ptr(losses)))
+        return losses
+
+    # ---- evaluate_model_single core (evaluate.py:640-743)
+    def render_frame(self, f):
+        rgb = np.empty((self.cfg.resy, self.cfg.resx, 3), np.float32)
+        sse = C.c_double(0)
+        self._chk(self.lib.af_render_frame(self.h, int(f), _ptr(rgb), C.byref(sse)))
+        return rgb, float(sse.value)
+
+    def psnr(self):
+        per = np.zeros(self.cfg.number_of_frames, np.float64)
+        mean = C.c_double(0)
+        self._chk(self.lib.af_psnr(self.h, C.byref(mean), _ptr(per)))
+        return float(mean.value), per
+
+    # ---- hooks
+    def debug_forward(self, net, rows):
+        rows = _f32(rows)
+        assert rows.ndim == 2 and rows.shape[1] == 4
+        out = np.empty_like(rows)
+        self._chk(self.lib.af_debug_forward(self.h, net, _ptr(rows), rows.shape[0], _ptr(out)))
+        return out
+
+    def set_debug(self, on=True):
+        self._chk(self.lib.af_set_debug(self.h, int(on)))
+
+    def last_grads(self, net):
+        g = np.empty(self.param_count(net), np.float32)
+        self._chk(self.lib.af_get_last_grads(self.h, net, _ptr(g), g.size))
+        return g
+
+    def set_timing(self, on=True):
+        self._chk(self.lib.af_set_timing(self.h, int(on)))
+
+    def timing(self, reset=True):
+        ms = np.zeros(8, np.float64); cnt = np.zeros(8, np.int64)
+        self._chk(self.lib.af_get_timing(self.h, _ptr(ms), _ptr(cnt), int(reset)))
+        names = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam")
+        return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt)}
+
+    def step_work(self, it):
+        rm, ra, fl = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        self._chk(self.lib.af_step_work(self.h, int(it), C.byref(rm), C.byref(ra), C.byref(fl)))
+        return int(rm.value), int(ra.value), float(fl.value)
+
+    def sync(self):
+        self._chk(self.lib.af_sync(self.h))

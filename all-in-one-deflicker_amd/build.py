@@ -1,0 +1,63 @@
+"""Build libatlasfit.so (HIP C++ for gfx950) in-tree with hipcc.  Usage: python build.py [--force]"""
+import os, subprocess, sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libatlasfit.so")
+UNITS = ["mlp.hip", "dw.hip", "elem.hip", "host.hip"]
+HEADERS = ["af_dev.h", "elem.h", os.path.join("..", "..", "include", "atlasfit.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(SRC, h) for h in HEADERS]
+    jobs = []
+    for u in UNITS:
+        src = os.path.join(SRC, u)
+        obj = os.path.join(objdir, u.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append(([_hipcc()] + FLAGS + ["-c", src, "-o", obj], u))
+
+    def run(job):
+        cmd, name = job
+        if verbose:
+            print("[build] hipcc", name, flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, u.replace(".hip", ".o")) for u in UNITS]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr)
+        if verbose:
+            print("[build] linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

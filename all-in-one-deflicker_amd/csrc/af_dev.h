@@ -1,0 +1,143 @@
+// af_dev.h — shared host/device definitions for the atlas-fit hot path (gfx950 / CDNA4 only).
+//
+// Layout vocabulary used by every kernel in this directory
+// --------------------------------------------------------
+// * row            one evaluation point of a coordinate MLP (a sampled (x,y,t) pixel or one of its
+//                  neighbours).  Rows are grouped in ROW TILES of 32 (the N dimension of
+//                  v_mfma_f32_32x32x2_f32).  One wavefront owns one row tile.
+// * C-layout       how a wave holds a 32-row x 256-feature activation block in registers: lane (j,h)
+//                  (j = lane&31 = row in tile, h = lane>>5) register rho = 16*T + 4*q + p holds feature
+//                  f = 32*T + 8*q + 4*h + p.  This is exactly the C/D fragment layout of the MFMA when the
+//                  layer is evaluated transposed (Y^T = W * X^T), and — because the K order of a dot product
+//                  is free — it is also a legal B-operand layout for the NEXT layer.  Activations therefore
+//                  never leave registers between layers.
+// * k-group g      8 consecutive reduction indices; lane-half h supplies indices 8g+4h+p, p=0..3, to four
+//                  consecutive MFMA steps.
+// * packed image   weights of one layer, ordered so that the A operand of those four steps is one 16-byte
+//                  LDS read: slot(g,h,m) = (2g+h)*Mpad + m holds A[m][8g+4h .. 8g+4h+3].
+// * T-layout       activations / gradients in HBM for the dW GEMM: per row tile, [feature][32 rows] floats.
+//
+// Reference: the networks are IMLP (src/models/stage_1/implicit_neural_networks.py:15-80).
+#pragma once
+#include <stdint.h>
+
+#define AF_HID        256           // hidden width (config number_of_channels_* — only 256 is built)
+#define AF_TROWS      32            // rows per tile
+#define AF_TILE_F     (AF_HID * AF_TROWS)       // floats per 256-feature T-layout tile
+#define AF_CHUNK_MAX  65536         // bytes per LDS weight buffer
+#define AF_MAX_LAYERS 8
+#define AF_MAX_NETS   4
+#define AF_REC_F      16            // floats per pixel record (64 B)
+
+enum { AF_NET_MAP1 = 0, AF_NET_ATLAS = 1, AF_NET_MAP2 = 2, AF_NET_ALPHA = 3 };
+enum { AF_IN_XYT = 0, AF_IN_PE2 = 1, AF_IN_PE3 = 2 };
+
+// pixel record field offsets (floats)
+enum { REC_RGB = 0, REC_DX = 3, REC_DY = 6, REC_FF = 9, REC_FB = 11, REC_MF = 13, REC_MB = 14, REC_FG = 15 };
+
+// dW job shapes: (out tiles, in tiles) of the layer block; per-wave split in dw.hip
+enum { DW_8x8 = 0, DW_8x2 = 1, DW_8x1 = 2, DW_1x8 = 3, DW_1x2 = 4 };
+
+struct AfChunk { uint32_t off; uint32_t bytes; };   // byte offset into the image buffer, multiple of 4096 bytes
+
+struct FwdArgs {
+  const float* wimg;          // forward packed image (all layers of this net)
+  const AfChunk* chunks;      // chunk table for this net (forward order)
+  const float* bias;          // [NL][256] padded biases
+  const float* in;            // [rows_pad][4]  xyt coords, or uv (PE nets use .x,.y[,.z])
+  float* out;                 // [rows_pad][4]  tanh outputs
+  float* acts;                // X_1..X_{NL-1}: [NL-1][NT][256][32]      (train only)
+  uint32_t* masks;            // relu bits:     [NL-1][NT][64][4]        (train only)
+  float* pe_tile;             // [NT][64][32] PE features in T-layout     (train only, PE nets)
+  float in_scale, in_shift0, in_shift1;   // PE nets: x = v*scale + (row < split_row ? shift0 : shift1)
+  int split_row;
+  int NT;                     // row tiles
+  int nchunks;
+};
+
+struct BwdArgs {
+  const float* wimg;          // backward packed image (W^T per layer)
+  const AfChunk* chunks;      // chunk table (backward order)
+  const float* out;           // [rows_pad][4] tanh outputs (forward)
+  const float* dout;          // [rows_pad][4] dL/d out
+  const uint32_t* masks;
+  float* dz;                  // dZ_0..dZ_{NL-2}: [NL-1][NT][256][32]
+  float* dz_last;             // [NT][32][32]
+  const float* pe_tile;       // [NT][64][32]
+  float* din0; float* din1;   // dL/d(input uv) accumulation targets ([rows][4]); rows>=split_row go to din1
+  float din_scale;
+  int split_row;
+  int nrows;                  // rows that own an input gradient (pad rows are skipped)
+  int NT;
+  int nchunks;
+};
+
+struct DwJob {
+  const float* A; const float* B;     // T-layout tensors (dZ_l and X_l)
+  uint32_t a_stride, b_stride;        // floats per row tile
+  int shape;                          // DW_*
+  uint32_t part_off;                  // float offset of slot 0 in the partial buffer
+  uint32_t part_blk;                  // floats per slot
+  int pad;
+};
+struct DwSeg { int job, t0, t1, slot; };
+#define DW_MAXSEG 16
+struct DwArgs {
+  const DwJob* jobs; const DwSeg* segs;   // segs: [gridDim.x][DW_MAXSEG], job<0 terminates
+  float* partial;
+};
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
+
+#define AF_DEV __device__ __forceinline__
+
+AF_DEV __amdgpu_buffer_rsrc_t af_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+AF_DEV float af_bl32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+AF_DEV f32x4 af_bl128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+AF_DEV void af_bs32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+AF_DEV void af_bs128(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+AF_DEV void af_glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+AF_DEV void af_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Stage one weight chunk (bytes multiple of 4096) into an LDS buffer; all 256 threads participate.
+AF_DEV void af_stage_chunk(const char* src, uint32_t bytes, char* dst, int tid, int wave) {
+  const int nit = (int)(bytes >> 12);
+  for (int it = 0; it < nit; ++it)
+    af_glds16(src + it * 4096 + tid * 16, dst + it * 4096 + wave * 1024);
+}
+
+// ---- PE slot <-> reference feature permutations -------------------------------------------------
+// Atlas (in_dim 2, 10 freqs): reference feature e = 4k + {sin x0, sin x1, cos x0, cos x1}
+// (implicit_neural_networks.py:9-13); slot == e (lane half h owns frequencies k = 2g+h).
+// Alpha (in_dim 3, 5 freqs): e = 6k + {sin x0..2, cos x0..2}; lane half h owns k in {2h, 2h+1}
+// plus the sin (h=0) / cos (h=1) triple of k=4.  Register rho = slot>>3*4 + slot&3, h = (slot>>2)&1.
+__host__ __device__ inline int af_pe_slot_of_feature(int pe_kind, int e) {
+  if (pe_kind != 2) return e;
+  int h, rho;
+  if (e < 24) { int k = e / 6, c = e % 6; h = k >> 1; rho = (k & 1) * 6 + c; }
+  else        { int c = e - 24; h = c / 3; rho = 12 + c % 3; }
+  return ((rho >> 2) << 3) + (h << 2) + (rho & 3);
+}
+// packed-image float index of element (m, k) in an image with row padding mpad
+__host__ __device__ inline uint32_t af_img_index(uint32_t mpad, uint32_t m, uint32_t k) {
+  return ((((k >> 3) * 2 + ((k >> 2) & 1)) * mpad + m) << 2) + (k & 3);
+}
+#endif  // __HIPCC__

@@ -1,0 +1,70 @@
+// elem.h — argument blocks of the non-GEMM kernels (see elem.hip).
+#pragma once
+#include "af_dev.h"
+
+struct PackArgs {
+  const float* frames;    // (resy, resx, 3, F)      reference layout, unwrap_utils.py:113
+  const float* flow_f;    // (resy, resx, 2, F[,1])  frame i -> i+1 at index i
+  const float* flow_b;    // (resy, resx, 2, F[,1])  frame j -> j-1 at index j
+  const float* mask_f;    // (resy, resx, F[,1])
+  const float* mask_b;
+  const float* mask_fg;   // (resy, resx, F) or null
+  float* table;           // [F*resy*resx][16]
+  int resx, resy, F;
+};
+
+struct PrepArgs {
+  const float* table;
+  const int64_t* inds;    // [N] pixel-frame indices of this iteration, or null -> device Philox
+  uint64_t seed; uint32_t iter;
+  int N, resx, resy, F;
+  float half_main, half_grad, half_frames;   // larger_dim/2, resx/2, F/2
+  int d_local, d_global, nseg;
+  float* coords;          // [rows_pad][4]
+  float* x0_tile;         // [NT][32][32]
+  float* samples;         // [N][16]
+  int* counts;            // [2]
+};
+
+struct LossArgs {
+  const float* samples; const float* out_map; const float* out_atlas;
+  float* dout_map; float* dout_atlas;
+  const int* counts;
+  float* loss_part;       // [nblocks][8]: rgb, gradient, rigidity, global rigidity, flow fwd, flow bwd (sums)
+  int N, nseg;
+  float L, uv_scale; int d_local, d_global;
+  float c_rgb, c_grad, c_rig, c_grig, c_flow;
+};
+
+struct PrePrepArgs {
+  const int64_t* ys; const int64_t* xs;   // host-provided rows/cols or null
+  uint64_t seed; uint32_t iter;
+  int N, resx, resy;
+  float half_main, t;
+  float* coords; float* x0_tile;
+};
+struct PreLossArgs { const float* coords; const float* out_map; float* dout_map; float* loss_part; int N; float uv_scale; };
+
+struct AdamJob {
+  uint32_t part_off, part_blk, nslots, pld;
+  uint32_t out_real, in_real, out_real_pad;
+  uint32_t p_off;       // flat param offset of W[0][col0]
+  uint32_t p_ld;        // in_features of the layer (canonical row length)
+  uint32_t col0;
+  int32_t  b_off;       // flat param offset of the bias, or -1 when another job of the layer owns it
+  uint32_t f_off;       // forward image: float offset of this layer's image
+  uint32_t f_mpad;
+  int32_t  b_img_off;   // backward image (W^T) float offset, or -1
+  uint32_t b_mpad;
+  uint32_t bias_img_off;// float offset in the padded bias array
+  uint32_t pe_kind;     // column -> slot permutation for columns >= hid_cols (0/1 identity, 2 alpha)
+  uint32_t hid_cols;    // leading identity-mapped columns of the LAYER (256 for skip layers, 0 for PE first layers, p_ld otherwise)
+};
+struct AdamHyper { float step_size, bc2_sqrt, one_minus_b1, beta2, one_minus_b2, eps; };
+struct AdamBufs { float* params; float* m; float* v; float* img_f; float* img_b; float* bias_img; };
+struct AdamArgs {
+  const AdamJob* jobs; const float* partial;
+  AdamBufs bufs; AdamHyper hy;
+  float* grad_out;           // optional: reduced gradient in flat param order (tests)
+  const float* loss_part; float* loss_out; int* counts; int loss_nblk;
+};

@@ -1,0 +1,392 @@
+// elem.hip — the non-GEMM kernels of the atlas-fit step: pixel-record table build, batch sampling +
+// gather + coordinate normalisation, the loss stack with its seed gradients, the pre-train loss,
+// split-K reduction + Adam, and the render / PSNR helpers.  All fp32, no fast-math (IEEE divide/sqrt,
+// accurate sinf/cosf/tanhf) — parity with the reference needs it (SURVEY.md §7 "Hard parts").
+#include "af_dev.h"
+#include "elem.h"
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (counter-based; one 128-bit block per (iteration, sample))
+AF_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+AF_DEV uint64_t af_rand_below(uint64_t seed, uint32_t iter, uint32_t n, uint32_t stream, uint64_t bound) {
+  uint32_t o[4];
+  philox4x32(n, iter, stream, 0x41544c53u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  const uint64_t r = ((uint64_t)o[1] << 32) | o[0];
+  return __umul64hi(r, bound);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixel-record table: 64-B records {rgb, d/dx rgb, d/dy rgb, fwd flow, bwd flow, fwd mask, bwd mask, fg mask}
+// from the reference's dense layouts (unwrap_utils.py:113-122,132-133).
+// record k = f*resy*resx + y*resx + x  (== column k of get_tuples' jif_all, unwrap_utils.py:166-173).
+__global__ void k_pack_table(PackArgs a) {
+  const size_t P2 = (size_t)a.resx * a.resy;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P2 * a.F) return;
+  const int f = (int)(idx % a.F);
+  const size_t pix = idx / a.F;
+  const int x = (int)(pix % a.resx), y = (int)(pix / a.resx);
+  const int F = a.F;
+  float rec[AF_REC_F];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = a.frames[(pix * 3 + c) * F + f];
+    rec[REC_RGB + c] = v;
+    rec[REC_DX + c] = (x + 1 < a.resx) ? a.frames[((pix + 1) * 3 + c) * F + f] - v : 0.f;
+    rec[REC_DY + c] = (y + 1 < a.resy) ? a.frames[((pix + a.resx) * 3 + c) * F + f] - v : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    rec[REC_FF + c] = a.flow_f[(pix * 2 + c) * F + f];
+    rec[REC_FB + c] = a.flow_b[(pix * 2 + c) * F + f];
+  }
+  rec[REC_MF] = a.mask_f[pix * F + f];
+  rec[REC_MB] = a.mask_b[pix * F + f];
+  rec[REC_FG] = a.mask_fg ? a.mask_fg[pix * F + f] : 0.f;
+  f32x4* dst = (f32x4*)(a.table + ((size_t)f * P2 + pix) * AF_REC_F);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { f32x4 v = {rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]}; dst[q] = v; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch preparation (stage1_neural_atlas.py:159-171; loss_utils.py:137-151, 230-233, 326-351).
+// Row segments of the mapping batch: 0 centre, 1 (x,y+1), 2 (x+1,y), 3 (x,y-d), 4 (x-d,y), 5 fwd-flow match,
+// 6 bwd-flow match, 7 (x,y-D), 8 (x-D,y); segments 7,8 exist only while the global rigidity term is on.
+AF_DEV void put_row(const PrepArgs& a, int seg, int n, float x, float y, float t) {
+  const size_t r = (size_t)seg * a.N + n;
+  f32x4 v = {x, y, t, 0.f};
+  *(f32x4*)(a.coords + r * 4) = v;
+  float* tl = a.x0_tile + (r >> 5) * 1024 + (r & 31);
+  tl[0] = x; tl[32] = y; tl[64] = t;
+}
+
+__global__ void k_prep(PrepArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int vf = 0, vb = 0;
+  if (n < a.N) {
+    const uint64_t P2 = (uint64_t)a.resx * a.resy;
+    const uint64_t k = a.inds ? (uint64_t)a.inds[n] : af_rand_below(a.seed, a.iter, (uint32_t)n, 0u, P2 * a.F);
+    const int f = (int)(k / P2);
+    const uint64_t rem = k - (uint64_t)f * P2;
+    const int y = (int)(rem / a.resx), x = (int)(rem - (uint64_t)y * a.resx);
+    const f32x4* rp = (const f32x4*)(a.table + k * AF_REC_F);
+    f32x4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    f32x4* sp = (f32x4*)(a.samples + (size_t)n * AF_REC_F);
+    sp[0] = r0; sp[1] = r1; sp[2] = r2; sp[3] = r3;
+    const float ffu = r2[1], ffv = r2[2], fbu = r2[3], fbv = r3[0], mf = r3[1], mb = r3[2];
+    const float hm = a.half_main, hg = a.half_grad, hf = a.half_frames;
+    const float xc = (float)x / hm - 1.f, yc = (float)y / hm - 1.f, tc = (float)f / hf - 1.f;
+    put_row(a, 0, n, xc, yc, tc);
+    put_row(a, 1, n, (float)x / hg - 1.f, (float)(y + 1) / hg - 1.f, tc);
+    put_row(a, 2, n, (float)(x + 1) / hg - 1.f, (float)y / hg - 1.f, tc);
+    put_row(a, 3, n, xc, (float)(y - a.d_local) / hm - 1.f, tc);
+    put_row(a, 4, n, (float)(x - a.d_local) / hm - 1.f, yc, tc);
+    vf = mf != 0.f; vb = mb != 0.f;
+    if (vf) put_row(a, 5, n, ((float)x + ffu) / hm - 1.f, ((float)y + ffv) / hm - 1.f, (float)(f + 1) / hf - 1.f);
+    else    put_row(a, 5, n, xc, yc, tc);
+    if (vb) put_row(a, 6, n, ((float)x + fbu) / hm - 1.f, ((float)y + fbv) / hm - 1.f, (float)(f - 1) / hf - 1.f);
+    else    put_row(a, 6, n, xc, yc, tc);
+    if (a.nseg > 7) {
+      put_row(a, 7, n, xc, (float)(y - a.d_global) / hm - 1.f, tc);
+      put_row(a, 8, n, (float)(x - a.d_global) / hm - 1.f, yc, tc);
+    }
+  }
+  const unsigned long long bf = __ballot(vf), bb = __ballot(vb);
+  if ((threadIdx.x & 63) == 0) {
+    if (bf) atomicAdd(a.counts + 0, __popcll(bf));
+    if (bb) atomicAdd(a.counts + 1, __popcll(bb));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+AF_DEV float block_sum(float v, float* red /*[4]*/) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct Rig { float loss, du, dv, du_xm, du_ym, dv_xm, dv_ym; };
+// Rigidity term and its gradient for one sample (loss_utils.py:239-278).
+AF_DEV Rig rigidity(float u, float v, float u_ym, float v_ym, float u_xm, float v_xm, float L, float s, float d, float w) {
+  const float j00 = ((u - u_xm) * L / 2.f) / s / d, j01 = ((u - u_ym) * L / 2.f) / s / d;
+  const float j10 = ((v - v_xm) * L / 2.f) / s / d, j11 = ((v - v_ym) * L / 2.f) / s / d;
+  const float g00 = j00 * j00 + j10 * j10, g01 = j00 * j01 + j10 * j11, g11 = j01 * j01 + j11 * j11;
+  const float A = g00 + 0.001f, D = g11 + 0.001f, B = g01;
+  const float det = A * D - B * B;
+  const float i00 = D / det, i01 = -B / det, i11 = A / det;
+  const float ng = sqrtf(g00 * g00 + 2.f * g01 * g01 + g11 * g11);
+  const float ni = sqrtf(i00 * i00 + 2.f * i01 * i01 + i11 * i11);
+  Rig r; r.loss = ng + ni;
+  // S = G/|G| - B^3/|B|  (B = inverse, symmetric)
+  const float b2_00 = i00 * i00 + i01 * i01, b2_01 = i00 * i01 + i01 * i11, b2_11 = i01 * i01 + i11 * i11;
+  const float b3_00 = b2_00 * i00 + b2_01 * i01, b3_01 = b2_00 * i01 + b2_01 * i11, b3_11 = b2_01 * i01 + b2_11 * i11;
+  const float rg = ng > 0.f ? 1.f / ng : 0.f, ri = ni > 0.f ? 1.f / ni : 0.f;
+  const float s00 = g00 * rg - b3_00 * ri, s01 = g01 * rg - b3_01 * ri, s11 = g11 * rg - b3_11 * ri;
+  // dl/dJ = 2 J S ; D = k * dl/dJ * w, k = (L/2)/(s d)
+  const float k = (L / 2.f) / s / d * w * 2.f;
+  const float d00 = k * (j00 * s00 + j01 * s01), d01 = k * (j00 * s01 + j01 * s11);
+  const float d10 = k * (j10 * s00 + j11 * s01), d11 = k * (j10 * s01 + j11 * s11);
+  r.du = d00 + d01; r.dv = d10 + d11; r.du_xm = -d00; r.du_ym = -d01; r.dv_xm = -d10; r.dv_ym = -d11;
+  return r;
+}
+
+AF_DEV void put_d2(float* dout, size_t row, float a, float b) { f32x4 v = {a, b, 0.f, 0.f}; *(f32x4*)(dout + row * 4) = v; }
+
+// Loss stack of the single-atlas path (stage1_neural_atlas.py:181-227; loss_utils.py:134-170,227-278,299-356)
+// + seed gradients wrt every network output row.
+__global__ __launch_bounds__(256) void k_loss_single(LossArgs a) {
+  __shared__ float red[4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  float l_rgb = 0.f, l_grad = 0.f, l_rig = 0.f, l_grig = 0.f, l_ff = 0.f, l_fb = 0.f;
+  if (n < a.N) {
+    const size_t N = a.N;
+    const float invN = 1.f / (float)a.N;
+    const float* sp = a.samples + (size_t)n * AF_REC_F;
+    const f32x4 uvc = *(const f32x4*)(a.out_map + (size_t)n * 4);
+    const f32x4 uvy1 = *(const f32x4*)(a.out_map + (N + n) * 4);       (void)uvy1;
+    float du = 0.f, dv = 0.f;
+    // ---- rgb + gradient terms
+    const f32x4 tc = *(const f32x4*)(a.out_atlas + (size_t)n * 4);
+    const f32x4 ty = *(const f32x4*)(a.out_atlas + (N + n) * 4);
+    const f32x4 tx = *(const f32x4*)(a.out_atlas + (2 * N + n) * 4);
+    float dtc[3], dty[3], dtx[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float rgb = (tc[c] + 1.f) * 0.5f, rgby = (ty[c] + 1.f) * 0.5f, rgbx = (tx[c] + 1.f) * 0.5f;
+      const float e = rgb - sp[REC_RGB + c];
+      const float rx = sp[REC_DX + c] - (rgbx - rgb), ry = sp[REC_DY + c] - (rgby - rgb);
+      l_rgb += e * e;
+      l_grad += rx * rx + ry * ry;
+      // d/d tanh-output = 1/2 d/d rgb
+      dtc[c] = 0.5f * (a.c_rgb * 2.f * e + a.c_grad * 2.f * (rx + ry)) * invN;
+      dtx[c] = 0.5f * (-a.c_grad * 2.f * rx) * invN;
+      dty[c] = 0.5f * (-a.c_grad * 2.f * ry) * invN;
+    }
+    { f32x4 v = {dtc[0], dtc[1], dtc[2], 0.f}; *(f32x4*)(a.dout_atlas + (size_t)n * 4) = v; }
+    { f32x4 v = {dty[0], dty[1], dty[2], 0.f}; *(f32x4*)(a.dout_atlas + (N + n) * 4) = v; }
+    { f32x4 v = {dtx[0], dtx[1], dtx[2], 0.f}; *(f32x4*)(a.dout_atlas + (2 * N + n) * 4) = v; }
+    put_d2(a.dout_map, N + n, 0.f, 0.f);        // (x,y+1) and (x+1,y) rows: gradient arrives from the atlas chain
+    put_d2(a.dout_map, 2 * N + n, 0.f, 0.f);
+    // ---- local rigidity
+    {
+      const f32x4 pym = *(const f32x4*)(a.out_map + (3 * N + n) * 4);
+      const f32x4 pxm = *(const f32x4*)(a.out_map + (4 * N + n) * 4);
+      const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale, (float)a.d_local, a.c_rig * invN);
+      l_rig = r.loss; du += r.du; dv += r.dv;
+      put_d2(a.dout_map, 3 * N + n, r.du_ym, r.dv_ym);
+      put_d2(a.dout_map, 4 * N + n, r.du_xm, r.dv_xm);
+    }
+    // ---- global rigidity
+    if (a.nseg > 7) {
+      const f32x4 pym = *(const f32x4*)(a.out_map + (7 * N + n) * 4);
+      const f32x4 pxm = *(const f32x4*)(a.out_map + (8 * N + n) * 4);
+      const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale, (float)a.d_global, a.c_grig * invN);
+      l_grig = r.loss; du += r.du; dv += r.dv;
+      put_d2(a.dout_map, 7 * N + n, r.du_ym, r.dv_ym);
+      put_d2(a.dout_map, 8 * N + n, r.du_xm, r.dv_xm);
+    }
+    // ---- optical flow (fwd: seg 5, count[0]; bwd: seg 6, count[1]); alpha == 1 in the single path
+    const float fscale = a.L / (2.f * a.uv_scale);
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const bool valid = sp[dir ? REC_MB : REC_MF] != 0.f;
+      const size_t row = (size_t)(5 + dir) * N + n;
+      float gu = 0.f, gv = 0.f;
+      if (valid) {
+        const f32x4 m = *(const f32x4*)(a.out_map + row * 4);
+        const float eu = m[0] - uvc[0], ev = m[1] - uvc[1];
+        const float nrm = sqrtf(eu * eu + ev * ev);
+        const float l = nrm * a.L / (2.f * a.uv_scale);
+        if (dir) l_fb = l; else l_ff = l;
+        const float cnt = (float)a.counts[dir];
+        const float w = nrm > 0.f ? a.c_flow * 0.5f * fscale / (nrm * cnt) : 0.f;
+        gu = w * eu; gv = w * ev;
+        du -= gu; dv -= gv;
+      }
+      put_d2(a.dout_map, row, gu, gv);
+    }
+    put_d2(a.dout_map, (size_t)n, du, dv);
+  }
+  float s[6] = {l_rgb, l_grad, l_rig, l_grig, l_ff, l_fb};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s[i] = block_sum(s[i], red);
+  if (threadIdx.x == 0) {
+    float* o = a.loss_part + (size_t)blockIdx.x * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = s[i];
+    o[6] = 0.f; o[7] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-train batch + loss (unwrap_utils.py:176-198): 10 000 random pixels of frame f,
+// loss = mean || s*(x,y) - M(x,y,t) ||_2.
+__global__ void k_pre_prep(PrePrepArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= a.N) return;
+  const int y = a.ys ? (int)a.ys[n] : (int)af_rand_below(a.seed, a.iter, (uint32_t)n, 1u, (uint64_t)a.resy);
+  const int x = a.xs ? (int)a.xs[n] : (int)af_rand_below(a.seed, a.iter, (uint32_t)n, 2u, (uint64_t)a.resx);
+  const float xc = (float)x / a.half_main - 1.f, yc = (float)y / a.half_main - 1.f;
+  f32x4 v = {xc, yc, a.t, 0.f};
+  *(f32x4*)(a.coords + (size_t)n * 4) = v;
+  float* tl = a.x0_tile + ((size_t)n >> 5) * 1024 + (n & 31);
+  tl[0] = xc; tl[32] = yc; tl[64] = a.t;
+}
+
+__global__ __launch_bounds__(256) void k_pre_loss(PreLossArgs a) {
+  __shared__ float red[4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (n < a.N) {
+    const f32x4 c = *(const f32x4*)(a.coords + (size_t)n * 4);
+    const f32x4 o = *(const f32x4*)(a.out_map + (size_t)n * 4);
+    const float eu = c[0] * a.uv_scale - o[0], ev = c[1] * a.uv_scale - o[1];
+    l = sqrtf(eu * eu + ev * ev);
+    const float w = l > 0.f ? -1.f / (l * (float)a.N) : 0.f;
+    put_d2(a.dout_map, (size_t)n, w * eu, w * ev);
+  }
+  l = block_sum(l, red);
+  if (threadIdx.x == 0) { float* o = a.loss_part + (size_t)blockIdx.x * 8; o[0] = l; for (int i = 1; i < 8; ++i) o[i] = 0.f; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K reduction + Adam (torch.optim.Adam defaults, stage1_neural_atlas.py:132-134,231) + re-emission
+// of the three weight views the GEMM kernels read (canonical, forward image, backward image).
+AF_DEV void emit_weight(const AdamJob& j, const AdamBufs& b, uint32_t o, uint32_t i, float p) {
+  const uint32_t col = j.col0 + i;
+  uint32_t k = col;
+  if (col >= j.hid_cols) k = j.hid_cols + (uint32_t)af_pe_slot_of_feature((int)j.pe_kind, (int)(col - j.hid_cols));
+  b.img_f[j.f_off + af_img_index(j.f_mpad, o, k)] = p;
+  if (j.b_img_off >= 0 && col < (j.hid_cols ? j.hid_cols : j.p_ld)) {
+    // W^T image: m = in feature (PE slot order for a PE first layer), k = out feature
+    const uint32_t mrow = j.hid_cols ? col : (uint32_t)af_pe_slot_of_feature((int)j.pe_kind, (int)col);
+    b.img_b[(uint32_t)j.b_img_off + af_img_index(j.b_mpad, mrow, o)] = p;
+  }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+  const AdamJob j = a.jobs[blockIdx.y];
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nw = j.out_real * j.in_real;
+  const uint32_t nb = j.b_off >= 0 ? j.out_real : 0u;
+  if (e < nw + nb) {
+    const bool is_bias = e >= nw;
+    const uint32_t o = is_bias ? e - nw : e / j.in_real;
+    const uint32_t i = is_bias ? 0u : e - o * j.in_real;
+    const uint32_t pidx = is_bias ? (uint32_t)j.b_off + o : j.p_off + o * j.p_ld + i;
+    float p = a.bufs.params[pidx];
+    if (UPDATE) {
+      const float* pp = a.partial + j.part_off + (is_bias ? j.out_real_pad * j.pld + o : o * j.pld + i);
+      float g = 0.f;
+      for (uint32_t s = 0; s < j.nslots; ++s) g += pp[(size_t)s * j.part_blk];
+      float m = a.bufs.m[pidx], v = a.bufs.v[pidx];
+      m = m + (g - m) * a.hy.one_minus_b1;
+      v = v * a.hy.beta2 + (a.hy.one_minus_b2 * g) * g;
+      const float denom = sqrtf(v) / a.hy.bc2_sqrt + a.hy.eps;
+      p = p - a.hy.step_size * (m / denom);
+      a.bufs.m[pidx] = m; a.bufs.v[pidx] = v; a.bufs.params[pidx] = p;
+      if (a.grad_out) a.grad_out[pidx] = g;
+    }
+    if (is_bias) a.bufs.bias_img[j.bias_img_off + o] = p;
+    else emit_weight(j, a.bufs, o, i, p);
+  }
+  if (UPDATE && blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {
+    // fold the per-block loss partials of this step (fixed order); report and reset the flow counters
+    if (threadIdx.x < 6) {
+      float s = 0.f;
+      for (int b = 0; b < a.loss_nblk; ++b) s += a.loss_part[b * 8 + threadIdx.x];
+      a.loss_out[threadIdx.x] = s;
+    } else if (threadIdx.x < 8) {
+      a.loss_out[threadIdx.x] = (float)a.counts[threadIdx.x - 6];
+      a.counts[threadIdx.x - 6] = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Render helpers (evaluate.py:640-661,705-743): coordinates of every pixel of a frame, rgb = (t+1)/2,
+// and the fp64 squared-error sum against the input frame for PSNR.
+__global__ void k_frame_coords(float* coords, int resx, int resy, float half_main, float t, int npix_pad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= npix_pad) return;
+  const int npix = resx * resy;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (r < npix) { const int y = r / resx, x = r - y * resx; v[0] = (float)x / half_main - 1.f; v[1] = (float)y / half_main - 1.f; v[2] = t; }
+  *(f32x4*)(coords + (size_t)r * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void k_frame_finish(const float* out_atlas, const float* table, float* rgb_out, double* sse_part,
+                                                     int npix, size_t rec0) {
+  __shared__ double red[4];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  double sse = 0.0;
+  if (r < npix) {
+    const f32x4 t = *(const f32x4*)(out_atlas + (size_t)r * 4);
+    const float* rec = table + (rec0 + r) * AF_REC_F;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = (t[c] + 1.f) * 0.5f;
+      rgb_out[(size_t)r * 3 + c] = v;
+      const double d = (double)rec[REC_RGB + c] - (double)v;
+      sse += d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
+  __syncthreads();
+  if (threadIdx.x == 0) sse_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+int af_launch_pack(const PackArgs* a, hipStream_t s) {
+  const size_t n = (size_t)a->resx * a->resy * a->F;
+  hipLaunchKernelGGL(k_pack_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_prep(const PrepArgs* a, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_loss_single(const LossArgs* a, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_single, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_pre_prep(const PrePrepArgs* a, hipStream_t s) {
+  hipLaunchKernelGGL(k_pre_prep, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_pre_loss(const PreLossArgs* a, hipStream_t s) {
+  hipLaunchKernelGGL(k_pre_loss, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_adam(const AdamArgs* a, int njobs, int update, hipStream_t s) {
+  const dim3 grid((AF_HID * 320 + AF_HID + 255) / 256, njobs);
+  if (update) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, s, *a);
+  else        hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_frame_coords(float* coords, int resx, int resy, float half_main, float t, int npix_pad, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_coords, dim3((npix_pad + 255) / 256), dim3(256), 0, s, coords, resx, resy, half_main, t, npix_pad);
+  return (int)hipGetLastError();
+}
+int af_launch_frame_finish(const float* out_atlas, const float* table, float* rgb_out, double* sse_part, int npix, size_t rec0, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_finish, dim3((npix + 255) / 256), dim3(256), 0, s, out_atlas, table, rgb_out, sse_part, npix, rec0);
+  return (int)hipGetLastError();
+}
+}

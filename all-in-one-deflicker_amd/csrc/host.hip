@@ -1,0 +1,792 @@
+// host.hip — handle, memory plan, dW schedule and the C ABI of libatlasfit.so (include/atlasfit.h).
+// The per-iteration loop body of the reference (src/stage1_neural_atlas.py:151-231) becomes eight kernel
+// launches on one stream: prep -> mapping fwd -> atlas fwd -> loss -> atlas bwd -> mapping bwd -> dW -> adam.
+// No host synchronisation inside the loop; the host only enqueues.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/atlasfit.h"
+#include "af_dev.h"
+#include "elem.h"
+
+extern "C" {
+int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s);
+int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s);
+int af_mlp_init();
+int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s);
+int af_dw_init();
+int af_launch_pack(const PackArgs* a, hipStream_t s);
+int af_launch_prep(const PrepArgs* a, hipStream_t s);
+int af_launch_loss_single(const LossArgs* a, hipStream_t s);
+int af_launch_pre_prep(const PrePrepArgs* a, hipStream_t s);
+int af_launch_pre_loss(const PreLossArgs* a, hipStream_t s);
+int af_launch_adam(const AdamArgs* a, int njobs, int update, hipStream_t s);
+int af_launch_frame_coords(float* coords, int resx, int resy, float half_main, float t, int npix_pad, hipStream_t s);
+int af_launch_frame_finish(const float* out_atlas, const float* table, float* rgb_out, double* sse_part, int npix, size_t rec0, hipStream_t s);
+}
+
+namespace {
+
+std::string g_create_error;
+
+struct NetDesc {
+  int id = -1, NL = 0, in_kind = 0, in_feat0 = 0, out = 0, pe_feats = 0, pe_kind = 0;
+  unsigned skip = 0; bool dx0 = false; bool used = false;
+  int in_feat[AF_MAX_LAYERS], out_feat[AF_MAX_LAYERS];
+  size_t w_off[AF_MAX_LAYERS], b_off[AF_MAX_LAYERS];   // within the net's flat params
+  size_t nparams = 0, p_base = 0;                       // p_base: offset in the global flat buffer
+  // images (float offsets into the global image buffers)
+  size_t f_off[AF_MAX_LAYERS]; int f_mpad[AF_MAX_LAYERS], f_groups[AF_MAX_LAYERS];
+  long long b_off_img[AF_MAX_LAYERS]; int b_mpad[AF_MAX_LAYERS];
+  size_t f_base = 0, b_base = 0, bias_base = 0;        // float offsets of this net's region (chunk offsets are relative to these)
+  std::vector<AfChunk> fchunks, bchunks;
+  AfChunk *d_fchunks = nullptr, *d_bchunks = nullptr;
+  // activations
+  int nt_cap = 0;
+  float *acts = nullptr, *dz = nullptr, *dz_last = nullptr, *pe_tile = nullptr, *out_buf = nullptr, *dout = nullptr;
+  uint32_t* masks = nullptr;
+};
+
+struct Sched {
+  std::vector<DwJob> jobs; std::vector<AdamJob> ajobs; std::vector<DwSeg> segs;
+  int nwg = 0; size_t partial_floats = 0;
+  DwJob* d_jobs = nullptr; AdamJob* d_ajobs = nullptr; DwSeg* d_segs = nullptr;
+};
+
+struct TimedEv { int cls; hipEvent_t a, b; };
+
+}  // namespace
+
+struct af_handle {
+  af_config cfg;
+  int device = 0; hipStream_t stream = nullptr; int ncu = 256;
+  std::string err;
+  NetDesc nets[AF_MAX_NETS];
+  size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0;
+  float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *pre_m = nullptr, *pre_v = nullptr, *grads = nullptr;
+  float *img_f = nullptr, *img_b = nullptr, *bias_img = nullptr;
+  long long adam_step = 0;
+  // video
+  float* table = nullptr; bool have_video = false;
+  // batch
+  int N = 0, rows_cap_map = 0, rows_cap_atlas = 0;
+  float *coords = nullptr, *x0_tile = nullptr, *samples = nullptr, *loss_part = nullptr, *loss_log = nullptr;
+  int* counts = nullptr; int loss_nblk = 0; size_t loss_log_cap = 0;
+  int cur_nseg = 0;
+  // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain map1, 3 = pretrain map2
+  Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
+  // render
+  int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
+  std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
+  bool debug = false, timing = false;
+  std::vector<TimedEv> evs; double t_ms[8] = {0}; long long t_cnt[8] = {0};
+
+  int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    err = buf;
+    return code;
+  }
+};
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return h->fail(AF_EHIP, #x, e_); } while (0)
+#define LCHK(x) do { int r_ = (x); if (r_ != 0) return h->fail(AF_EHIP, #x, (hipError_t)r_); } while (0)
+
+namespace {
+
+template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
+
+void describe_net(NetDesc& n, int id, int NL, int in_kind, int pe_freqs, int out, unsigned skip, bool dx0) {
+  n.id = id; n.NL = NL; n.in_kind = in_kind; n.out = out; n.skip = skip; n.dx0 = dx0; n.used = true;
+  const int in_dim = in_kind == AF_IN_PE2 ? 2 : 3;
+  n.pe_feats = in_kind == AF_IN_XYT ? 0 : 2 * in_dim * pe_freqs;
+  n.pe_kind = in_kind == AF_IN_PE3 ? 2 : (in_kind == AF_IN_PE2 ? 1 : 0);
+  n.in_feat0 = in_kind == AF_IN_XYT ? 3 : n.pe_feats;
+  size_t off = 0;
+  for (int l = 0; l < NL; ++l) {
+    n.in_feat[l] = l == 0 ? n.in_feat0 : (AF_HID + (((skip >> l) & 1) ? n.pe_feats : 0));
+    n.out_feat[l] = l == NL - 1 ? out : AF_HID;
+    n.w_off[l] = off; off += (size_t)n.in_feat[l] * n.out_feat[l];
+    n.b_off[l] = off; off += n.out_feat[l];
+  }
+  n.nparams = off;
+}
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Lay out the forward and backward packed images of one net and their chunk tables.
+void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cursor) {
+  n.f_base = f_cursor; n.b_base = b_cursor; n.bias_base = bias_cursor;
+  bias_cursor += (size_t)n.NL * AF_HID;
+  const int peg = (n.pe_feats + 7) / 8;
+  size_t foff = 0;   // bytes relative to f_base
+  for (int l = 0; l < n.NL; ++l) {
+    const bool last = l == n.NL - 1;
+    const int mpad = last ? 32 : AF_HID;
+    const int groups = (l == 0) ? (n.in_kind == AF_IN_XYT ? 1 : peg) : (32 + (((n.skip >> l) & 1) ? peg : 0));
+    n.f_mpad[l] = mpad; n.f_groups[l] = groups;
+    n.f_off[l] = n.f_base + foff / 4;
+    const size_t gbytes = (size_t)2 * mpad * 16;
+    if (l == 0 || last) {
+      const size_t bytes = round_up(groups * gbytes, 4096);
+      n.fchunks.push_back({(uint32_t)foff, (uint32_t)bytes});
+      foff += bytes;
+    } else {
+      for (int c = 0; c < 4; ++c) { n.fchunks.push_back({(uint32_t)foff, (uint32_t)(8 * gbytes)}); foff += 8 * gbytes; }
+      if ((n.skip >> l) & 1) { const size_t bytes = round_up(peg * gbytes, 4096); n.fchunks.push_back({(uint32_t)foff, (uint32_t)bytes}); foff += bytes; }
+    }
+  }
+  f_cursor += foff / 4;
+  size_t boff = 0;
+  for (int l = 0; l < n.NL; ++l) { n.b_off_img[l] = -1; n.b_mpad[l] = 0; }
+  for (int l = n.NL - 1; l >= (n.dx0 ? 0 : 1); --l) {
+    const int mpad = l == 0 ? 64 : AF_HID;
+    const int groups = l == n.NL - 1 ? 1 : 32;
+    n.b_mpad[l] = mpad; n.b_off_img[l] = (long long)(n.b_base + boff / 4);
+    const size_t gbytes = (size_t)2 * mpad * 16;
+    if (groups * gbytes <= AF_CHUNK_MAX) { n.bchunks.push_back({(uint32_t)boff, (uint32_t)(groups * gbytes)}); boff += groups * gbytes; }
+    else for (int c = 0; c < 4; ++c) { n.bchunks.push_back({(uint32_t)boff, (uint32_t)(8 * gbytes)}); boff += 8 * gbytes; }
+  }
+  b_cursor += boff / 4;
+}
+
+int shape_tiles(int shape, int& To, int& Ti) {
+  switch (shape) {
+    case DW_8x8: To = 8; Ti = 8; return 256;
+    case DW_8x2: To = 8; Ti = 2; return 64;
+    case DW_8x1: To = 8; Ti = 1; return 32;
+    case DW_1x8: To = 1; Ti = 8; return 32;
+    default:     To = 1; Ti = 2; return 16;
+  }
+}
+
+struct NetUse { NetDesc* n; int NT; };
+
+// Build the dW job list, the Adam job list and the cost-balanced split-K schedule for a set of nets.
+bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses, float* x0_tile) {
+  sc.jobs.clear(); sc.ajobs.clear(); sc.segs.clear();
+  std::vector<int> job_nt;
+  auto add = [&](NetDesc& n, int NT, int l, int shape, const float* A, uint32_t as, const float* B, uint32_t bs,
+                 int col0, int in_real, bool owns_bias) {
+    int To, Ti; shape_tiles(shape, To, Ti);
+    DwJob j{}; j.A = A; j.B = B; j.a_stride = as; j.b_stride = bs; j.shape = shape;
+    j.part_blk = (uint32_t)(To * 32 * Ti * 32 + To * 32);
+    sc.jobs.push_back(j); job_nt.push_back(NT);
+    AdamJob a{};
+    a.part_blk = j.part_blk; a.pld = Ti * 32; a.out_real = n.out_feat[l]; a.in_real = in_real; a.out_real_pad = To * 32;
+    a.p_off = (uint32_t)(n.p_base + n.w_off[l] + col0); a.p_ld = n.in_feat[l]; a.col0 = col0;
+    a.b_off = owns_bias ? (int32_t)(n.p_base + n.b_off[l]) : -1;
+    a.f_off = (uint32_t)n.f_off[l]; a.f_mpad = n.f_mpad[l];
+    a.b_img_off = (int32_t)n.b_off_img[l]; a.b_mpad = n.b_mpad[l];
+    a.bias_img_off = (uint32_t)(n.bias_base + (size_t)l * AF_HID);
+    a.pe_kind = n.pe_kind;
+    a.hid_cols = l == 0 ? (n.in_kind == AF_IN_XYT ? n.in_feat[l] : 0) : AF_HID;
+    sc.ajobs.push_back(a);
+  };
+  for (const NetUse& u : uses) {
+    NetDesc& n = *u.n; const int NT = u.NT;
+    const size_t ts = (size_t)NT * AF_TILE_F;
+    for (int l = 0; l < n.NL; ++l) {
+      const bool last = l == n.NL - 1, sk = (n.skip >> l) & 1;
+      if (l == 0) {
+        if (n.in_kind == AF_IN_XYT) add(n, NT, 0, DW_8x1, n.dz, AF_TILE_F, x0_tile, 1024, 0, 3, true);
+        else                        add(n, NT, 0, DW_8x2, n.dz, AF_TILE_F, n.pe_tile, 2048, 0, n.pe_feats, true);
+      } else if (!last) {
+        add(n, NT, l, DW_8x8, n.dz + l * ts, AF_TILE_F, n.acts + (l - 1) * ts, AF_TILE_F, 0, AF_HID, true);
+        if (sk) add(n, NT, l, DW_8x2, n.dz + l * ts, AF_TILE_F, n.pe_tile, 2048, AF_HID, n.pe_feats, false);
+      } else {
+        add(n, NT, l, DW_1x8, n.dz_last, 1024, n.acts + (l - 1) * ts, AF_TILE_F, 0, AF_HID, true);
+        if (sk) add(n, NT, l, DW_1x2, n.dz_last, 1024, n.pe_tile, 2048, AF_HID, n.pe_feats, false);
+      }
+    }
+  }
+  const int nj = (int)sc.jobs.size();
+  auto tile_cost = [&](int j) { int To, Ti; return (double)shape_tiles(sc.jobs[j].shape, To, Ti) + 20.0; };
+  const double seg_cost = 60.0;
+  double total = 0;
+  for (int j = 0; j < nj; ++j) total += tile_cost(j) * job_nt[j] + seg_cost;
+  int nwg = (int)std::min<double>(h->ncu, std::max(1.0, total / (16.0 * 276.0)));
+  std::vector<int> order(nj);
+  for (int j = 0; j < nj; ++j) order[j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tile_cost(a) * job_nt[a] > tile_cost(b) * job_nt[b]; });
+  std::vector<int> nslots(nj, 0);
+  std::vector<std::vector<DwSeg>> wg(nwg);
+  const double target = total / nwg;
+  int w = 0; double fill = 0;
+  for (int oi = 0; oi < nj; ++oi) {
+    const int j = order[oi]; int t = 0; const double tc = tile_cost(j);
+    while (t < job_nt[j]) {
+      if (w < nwg - 1 && (fill + seg_cost + tc > target || (int)wg[w].size() >= DW_MAXSEG - 1)) { ++w; fill = 0; }
+      double room = target - fill - seg_cost;
+      int take = w == nwg - 1 ? job_nt[j] - t : (int)std::max(1.0, floor(room / tc));
+      take = std::min(take, job_nt[j] - t);
+      wg[w].push_back({j, t, t + take, nslots[j]++});
+      fill += seg_cost + tc * take; t += take;
+    }
+  }
+  sc.nwg = nwg;
+  for (int i = 0; i < nwg; ++i) if (wg[i].size() > DW_MAXSEG) return false;
+  sc.segs.assign((size_t)nwg * DW_MAXSEG, DwSeg{-1, 0, 0, 0});
+  for (int i = 0; i < nwg; ++i)
+    for (size_t s = 0; s < wg[i].size() && s < DW_MAXSEG; ++s) sc.segs[(size_t)i * DW_MAXSEG + s] = wg[i][s];
+  size_t off = 0;
+  for (int j = 0; j < nj; ++j) {
+    sc.jobs[j].part_off = (uint32_t)off; sc.ajobs[j].part_off = (uint32_t)off; sc.ajobs[j].nslots = nslots[j];
+    off += (size_t)nslots[j] * sc.jobs[j].part_blk;
+  }
+  sc.partial_floats = off;
+  return true;
+}
+
+hipError_t upload_sched(Sched& sc) {
+  hipError_t e;
+  if (sc.d_jobs) { (void)hipFree(sc.d_jobs); (void)hipFree(sc.d_ajobs); (void)hipFree(sc.d_segs); sc.d_jobs = nullptr; }
+  if ((e = dalloc(&sc.d_jobs, sc.jobs.size())) != hipSuccess) return e;
+  if ((e = dalloc(&sc.d_ajobs, sc.ajobs.size())) != hipSuccess) return e;
+  if ((e = dalloc(&sc.d_segs, sc.segs.size())) != hipSuccess) return e;
+  if ((e = hipMemcpy(sc.d_jobs, sc.jobs.data(), sc.jobs.size() * sizeof(DwJob), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipMemcpy(sc.d_ajobs, sc.ajobs.data(), sc.ajobs.size() * sizeof(AdamJob), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  return hipMemcpy(sc.d_segs, sc.segs.data(), sc.segs.size() * sizeof(DwSeg), hipMemcpyHostToDevice);
+}
+
+int tiles_of(int rows) { return (rows + 31) / 32; }
+
+hipError_t alloc_net_buffers(NetDesc& n, int rows_cap) {
+  n.nt_cap = tiles_of(rows_cap);
+  const size_t nt = n.nt_cap, rp = nt * 32;
+  hipError_t e;
+  if ((e = dalloc(&n.acts, (size_t)(n.NL - 1) * nt * AF_TILE_F)) != hipSuccess) return e;
+  if ((e = dalloc(&n.dz, (size_t)(n.NL - 1) * nt * AF_TILE_F)) != hipSuccess) return e;
+  if ((e = dalloc(&n.masks, (size_t)(n.NL - 1) * nt * 64 * 4)) != hipSuccess) return e;
+  if ((e = dalloc(&n.dz_last, nt * 1024)) != hipSuccess) return e;
+  if ((e = dalloc(&n.pe_tile, n.pe_feats ? nt * 2048 : 1)) != hipSuccess) return e;
+  if ((e = dalloc(&n.out_buf, rp * 4)) != hipSuccess) return e;
+  if ((e = dalloc(&n.dout, rp * 4)) != hipSuccess) return e;
+  if ((e = hipMemset(n.dz_last, 0, nt * 1024 * 4)) != hipSuccess) return e;
+  if (n.pe_feats && (e = hipMemset(n.pe_tile, 0, nt * 2048 * 4)) != hipSuccess) return e;
+  if ((e = hipMemset(n.out_buf, 0, rp * 16)) != hipSuccess) return e;
+  return hipMemset(n.dout, 0, rp * 16);
+}
+
+void free_net(NetDesc& n) {
+  (void)hipFree(n.acts); (void)hipFree(n.dz); (void)hipFree(n.masks); (void)hipFree(n.dz_last); (void)hipFree(n.pe_tile); (void)hipFree(n.out_buf); (void)hipFree(n.dout);
+  (void)hipFree(n.d_fchunks); (void)hipFree(n.d_bchunks);
+}
+
+FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train) {
+  FwdArgs a{};
+  a.wimg = h->img_f + n.f_base; a.chunks = n.d_fchunks; a.bias = h->bias_img + n.bias_base;
+  a.in = in; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
+  a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
+  a.NT = NT; a.nchunks = (int)n.fchunks.size();
+  return a;
+}
+
+BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
+  BwdArgs a{};
+  a.wimg = h->img_b + n.b_base; a.chunks = n.d_bchunks; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
+  a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
+  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nchunks = (int)n.bchunks.size();
+  return a;
+}
+
+struct Timer {
+  af_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr;
+  Timer(af_handle* h_, int c) : h(h_), cls(c) {
+    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+  }
+  ~Timer() { if (h->timing) { hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); } }
+};
+
+void drain_timers(af_handle* h) {
+  for (TimedEv& e : h->evs) {
+    float ms = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&ms, e.a, e.b);
+    h->t_ms[e.cls] += ms; h->t_cnt[e.cls] += 1;
+    hipEventDestroy(e.a); hipEventDestroy(e.b);
+  }
+  h->evs.clear();
+}
+
+AdamHyper adam_hyper(double lr, long long step) {
+  const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  AdamHyper hy;
+  hy.step_size = (float)(lr / bc1); hy.bc2_sqrt = (float)sqrt(bc2);
+  hy.one_minus_b1 = (float)(1.0 - b1); hy.beta2 = (float)b2; hy.one_minus_b2 = (float)(1.0 - b2); hy.eps = (float)eps;
+  return hy;
+}
+
+int ensure_partial(af_handle* h, size_t floats) {
+  if (floats <= h->partial_cap) return 0;
+  if (h->partial) (void)hipFree(h->partial);
+  h->partial = nullptr; h->partial_cap = 0;
+  HCHK(dalloc(&h->partial, floats));
+  h->partial_cap = floats;
+  return 0;
+}
+
+// re-emit the GEMM weight views of the jobs of a schedule from the canonical parameters
+int repack(af_handle* h, Sched& sc) {
+  AdamArgs a{};
+  a.jobs = sc.d_ajobs; a.partial = h->partial;
+  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img};
+  LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 0, h->stream));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* af_last_error(const af_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
+  if (!cfg || !out) { g_create_error = "af_create: null argument"; return AF_EINVAL; }
+  *out = nullptr;
+  auto bad = [&](const char* m) { g_create_error = std::string("af_create: ") + m; return (int)AF_EINVAL; };
+  if (cfg->resx <= 1 || cfg->resy <= 1 || cfg->number_of_frames <= 0) return bad("resx/resy/number_of_frames");
+  if (cfg->samples_batch <= 0) return bad("samples_batch");
+  if (cfg->number_of_channels_mapping1 != AF_HID || cfg->number_of_channels_atlas != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:19,24)");
+  if (cfg->number_of_layers_mapping1 != 6 || cfg->number_of_layers_atlas != 8) return bad("only 6-layer mapping / 8-layer atlas nets are built (config_flow_100.json:20,25)");
+  if (cfg->positional_encoding_num_atlas != 10) return bad("positional_encoding_num_atlas must be 10");
+  if (cfg->use_positional_encoding_mapping1) return bad("use_positional_encoding_mapping1=true is not built");
+  if (!cfg->use_gradient_loss) return bad("use_gradient_loss=false is not built");
+  if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
+  hipError_t e = hipSetDevice(device_ordinal);
+  if (e != hipSuccess) { g_create_error = std::string("af_create: hipSetDevice: ") + hipGetErrorString(e); return AF_EHIP; }
+  af_handle* h = new af_handle();
+  h->cfg = *cfg; h->device = device_ordinal;
+  if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
+  if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
+  auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
+#define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->fail(AF_EHIP, #x, e_); return die(e_ == hipErrorOutOfMemory ? AF_ENOMEM : AF_EHIP); } } while (0)
+  hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
+  h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CCHK(hipStreamCreate(&h->stream));
+  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_dw_init());
+
+  describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
+  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
+  size_t fc = 0, bc = 0, biasc = 0, pc = 0;
+  for (NetDesc& n : h->nets) if (n.used) { n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc); }
+  h->total_params = pc; h->img_f_floats = fc; h->img_b_floats = bc; h->bias_floats = biasc;
+  CCHK(dalloc(&h->params, pc)); CCHK(dalloc(&h->adam_m, pc)); CCHK(dalloc(&h->adam_v, pc));
+  CCHK(dalloc(&h->pre_m, pc)); CCHK(dalloc(&h->pre_v, pc)); CCHK(dalloc(&h->grads, pc));
+  CCHK(dalloc(&h->img_f, fc)); CCHK(dalloc(&h->img_b, bc)); CCHK(dalloc(&h->bias_img, biasc));
+  CCHK(hipMemset(h->params, 0, pc * 4)); CCHK(hipMemset(h->adam_m, 0, pc * 4)); CCHK(hipMemset(h->adam_v, 0, pc * 4));
+  CCHK(hipMemset(h->pre_m, 0, pc * 4)); CCHK(hipMemset(h->pre_v, 0, pc * 4)); CCHK(hipMemset(h->grads, 0, pc * 4));
+  CCHK(hipMemset(h->img_f, 0, fc * 4)); CCHK(hipMemset(h->img_b, 0, bc * 4)); CCHK(hipMemset(h->bias_img, 0, biasc * 4));
+  for (NetDesc& n : h->nets) if (n.used) {
+    CCHK(dalloc(&n.d_fchunks, n.fchunks.size())); CCHK(dalloc(&n.d_bchunks, n.bchunks.size()));
+    CCHK(hipMemcpy(n.d_fchunks, n.fchunks.data(), n.fchunks.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(n.d_bchunks, n.bchunks.data(), n.bchunks.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
+  }
+  // batch buffers
+  h->N = cfg->samples_batch;
+  const int rows_full = 9 * h->N, rows_pre = h->cfg.pretrain_batch;
+  h->rows_cap_map = std::max(rows_full, rows_pre);
+  h->rows_cap_atlas = 3 * h->N;
+  CCHK(alloc_net_buffers(h->nets[AF_NET_MAP1], h->rows_cap_map));
+  CCHK(alloc_net_buffers(h->nets[AF_NET_ATLAS], h->rows_cap_atlas));
+  const size_t ntm = tiles_of(h->rows_cap_map);
+  CCHK(dalloc(&h->coords, ntm * 32 * 4)); CCHK(hipMemset(h->coords, 0, ntm * 32 * 16));
+  CCHK(dalloc(&h->x0_tile, ntm * 1024)); CCHK(hipMemset(h->x0_tile, 0, ntm * 4096));
+  CCHK(dalloc(&h->samples, (size_t)h->N * AF_REC_F));
+  h->loss_nblk = (std::max(h->N, rows_pre) + 255) / 256;
+  CCHK(dalloc(&h->loss_part, (size_t)h->loss_nblk * 8)); CCHK(hipMemset(h->loss_part, 0, (size_t)h->loss_nblk * 32));
+  CCHK(dalloc(&h->counts, 2)); CCHK(hipMemset(h->counts, 0, 8));
+  // schedules
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
+  if (!build_sched(h, h->sched[0], {{&M, tiles_of(9 * h->N)}, {&A, tiles_of(3 * h->N)}}, h->x0_tile) ||
+      !build_sched(h, h->sched[1], {{&M, tiles_of(7 * h->N)}, {&A, tiles_of(3 * h->N)}}, h->x0_tile) ||
+      !build_sched(h, h->sched[2], {{&M, tiles_of(rows_pre)}}, h->x0_tile)) { h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup"); return die(AF_EINVAL); }
+  size_t pf = 0;
+  for (int i = 0; i < 3; ++i) { CCHK(upload_sched(h->sched[i])); pf = std::max(pf, h->sched[i].partial_floats); }
+  CCHK(dalloc(&h->partial, pf)); h->partial_cap = pf;
+  h->frame_sse.assign(cfg->number_of_frames, 0.0); h->frame_sse_valid.assign(cfg->number_of_frames, 0);
+  if (repack(h, h->sched[0]) != 0) return die(AF_EHIP);
+  CCHK(hipStreamSynchronize(h->stream));
+#undef CCHK
+  *out = h;
+  return AF_OK;
+}
+
+void af_destroy(af_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  drain_timers(h);
+  for (NetDesc& n : h->nets) if (n.used) free_net(n);
+  for (Sched& s : h->sched) { (void)hipFree(s.d_jobs); (void)hipFree(s.d_ajobs); (void)hipFree(s.d_segs); }
+  (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
+  (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table);
+  (void)hipFree(h->coords); (void)hipFree(h->x0_tile); (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
+  (void)hipFree(h->partial); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int af_sync(af_handle* h) {
+  if (!h) return AF_EINVAL;
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  return AF_OK;
+}
+
+int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, const float* flow_bwd,
+                    const float* mask_fwd, const float* mask_bwd, const float* mask_fg, int on_device) {
+  if (!h) return AF_EINVAL;
+  if (!frames || !flow_fwd || !flow_bwd || !mask_fwd || !mask_bwd) return h->fail(AF_EINVAL, "af_upload_video: null tensor");
+  HCHK(hipSetDevice(h->device));
+  const size_t P2 = (size_t)h->cfg.resx * h->cfg.resy, F = h->cfg.number_of_frames, P = P2 * F;
+  if (!h->table) { hipError_t e = dalloc(&h->table, P * AF_REC_F); if (e != hipSuccess) return h->fail(AF_ENOMEM, "record table", e); }
+  const float* src[6] = {frames, flow_fwd, flow_bwd, mask_fwd, mask_bwd, mask_fg};
+  const size_t cnt[6] = {P * 3, P * 2, P * 2, P, P, P};
+  float* tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const float* dev[6];
+  int rc = AF_OK;
+  for (int i = 0; i < 6 && rc == AF_OK; ++i) {
+    if (!src[i]) { dev[i] = nullptr; continue; }
+    if (on_device) { dev[i] = src[i]; continue; }
+    hipError_t e = dalloc(&tmp[i], cnt[i]);
+    if (e == hipSuccess) e = hipMemcpy(tmp[i], src[i], cnt[i] * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = h->fail(e == hipErrorOutOfMemory ? AF_ENOMEM : AF_EHIP, "af_upload_video staging", e);
+    dev[i] = tmp[i];
+  }
+  if (rc == AF_OK) {
+    PackArgs a{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], h->table, h->cfg.resx, h->cfg.resy, h->cfg.number_of_frames};
+    int r = af_launch_pack(&a, h->stream);
+    hipError_t e = r ? (hipError_t)r : hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = h->fail(AF_EHIP, "pack table", e);
+  }
+  for (int i = 0; i < 6; ++i) if (tmp[i]) (void)hipFree(tmp[i]);
+  if (rc == AF_OK) { h->have_video = true; std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0); }
+  return rc;
+}
+
+size_t af_param_count(const af_handle* h, int net) {
+  if (!h || net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return 0;
+  return h->nets[net].nparams;
+}
+
+static int check_net(af_handle* h, int net, size_t n) {
+  if (!h) return AF_EINVAL;
+  if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
+  if (n != h->nets[net].nparams) return h->fail(AF_EINVAL, "parameter count mismatch");
+  return AF_OK;
+}
+
+int af_set_params(af_handle* h, int net, const float* flat, size_t n) {
+  int rc = check_net(h, net, n); if (rc) return rc;
+  if (!flat) return h->fail(AF_EINVAL, "af_set_params: null");
+  HCHK(hipSetDevice(h->device));
+  HCHK(hipStreamSynchronize(h->stream));
+  HCHK(hipMemcpy(h->params + h->nets[net].p_base, flat, n * 4, hipMemcpyHostToDevice));
+  rc = repack(h, h->sched[0]); if (rc) return rc;
+  HCHK(hipStreamSynchronize(h->stream));
+  std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
+  return AF_OK;
+}
+
+int af_get_params(af_handle* h, int net, float* flat, size_t n) {
+  int rc = check_net(h, net, n); if (rc) return rc;
+  if (!flat) return h->fail(AF_EINVAL, "af_get_params: null");
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  HCHK(hipMemcpy(flat, h->params + h->nets[net].p_base, n * 4, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+int af_get_adam_state(af_handle* h, int net, float* m, float* v, int64_t* step) {
+  if (!h) return AF_EINVAL;
+  if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  const NetDesc& n = h->nets[net];
+  if (m) HCHK(hipMemcpy(m, h->adam_m + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost));
+  if (v) HCHK(hipMemcpy(v, h->adam_v + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost));
+  if (step) *step = h->adam_step;
+  return AF_OK;
+}
+
+int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int64_t step) {
+  if (!h) return AF_EINVAL;
+  if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
+  if (step < 0) return h->fail(AF_EINVAL, "negative step");
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  const NetDesc& n = h->nets[net];
+  if (m) HCHK(hipMemcpy(h->adam_m + n.p_base, m, n.nparams * 4, hipMemcpyHostToDevice));
+  if (v) HCHK(hipMemcpy(h->adam_v + n.p_base, v, n.nparams * 4, hipMemcpyHostToDevice));
+  h->adam_step = step;
+  return AF_OK;
+}
+
+int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
+int af_set_timing(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->timing = enable != 0; return AF_OK; }
+int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset) {
+  if (!h) return AF_EINVAL;
+  hipSetDevice(h->device); hipStreamSynchronize(h->stream); drain_timers(h);
+  for (int i = 0; i < 8; ++i) { if (ms8) ms8[i] = h->t_ms[i]; if (counts8) counts8[i] = h->t_cnt[i]; if (reset) { h->t_ms[i] = 0; h->t_cnt[i] = 0; } }
+  return AF_OK;
+}
+
+int af_get_last_grads(af_handle* h, int net, float* flat, size_t n) {
+  int rc = check_net(h, net, n); if (rc) return rc;
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  HCHK(hipMemcpy(flat, h->grads + h->nets[net].p_base, n * 4, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+static int ensure_loss_log(af_handle* h, size_t steps) {
+  if (steps * 8 <= h->loss_log_cap) return 0;
+  if (h->loss_log) (void)hipFree(h->loss_log);
+  h->loss_log = nullptr; h->loss_log_cap = 0;
+  HCHK(dalloc(&h->loss_log, steps * 8));
+  h->loss_log_cap = steps * 8;
+  return 0;
+}
+
+// One backward + update tail shared by the main loop and the pre-train: chains, dW, Adam.
+static int step_tail(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, bool with_atlas, int NT_map, int NT_atlas, int rows_atlas) {
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
+  if (with_atlas) {
+    Timer t(h, 4);
+    BwdArgs b = bwd_args(h, A, NT_atlas);
+    b.din0 = M.dout; b.nrows = rows_atlas;
+    LCHK(af_launch_bwd(AF_NET_ATLAS, &b, h->stream));
+  }
+  { Timer t(h, 5); BwdArgs b = bwd_args(h, M, NT_map); LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream)); }
+  { Timer t(h, 6); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
+  {
+    Timer t(h, 7);
+    AdamArgs a{};
+    a.jobs = sc.d_ajobs; a.partial = h->partial;
+    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img};
+    a.hy = adam_hyper(h->cfg.lr, step);
+    a.grad_out = h->debug ? h->grads : nullptr;
+    a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = (h->N + 255) / 256;
+    LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 1, h->stream));
+  }
+  return 0;
+}
+
+int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, const int64_t* xs, uint64_t seed, float* losses_out) {
+  if (!h) return AF_EINVAL;
+  if (net != AF_MAPPING1) return h->fail(AF_EINVAL, "af_pretrain: only AF_MAPPING1 is built in this configuration");
+  if (pretrain_iters < 0 || ((ys == nullptr) != (xs == nullptr))) return h->fail(AF_EINVAL, "af_pretrain: arguments");
+  HCHK(hipSetDevice(h->device));
+  const int F = h->cfg.number_of_frames, NB = h->cfg.pretrain_batch;
+  const size_t steps = (size_t)pretrain_iters * F;
+  if (steps == 0) return AF_OK;
+  NetDesc& M = h->nets[AF_NET_MAP1];
+  Sched& sc = h->sched[2];
+  int rc = ensure_loss_log(h, steps); if (rc) return rc;
+  int64_t *d_ys = nullptr, *d_xs = nullptr;
+  if (ys) {
+    HCHK(dalloc(&d_ys, steps * NB)); HCHK(dalloc(&d_xs, steps * NB));
+    HCHK(hipMemcpy(d_ys, ys, steps * NB * 8, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(d_xs, xs, steps * NB * 8, hipMemcpyHostToDevice));
+  }
+  const int NT = tiles_of(NB);
+  HCHK(hipMemsetAsync(M.dout, 0, (size_t)M.nt_cap * 32 * 16, h->stream));
+  HCHK(hipMemsetAsync(h->pre_m, 0, h->total_params * 4, h->stream));
+  HCHK(hipMemsetAsync(h->pre_v, 0, h->total_params * 4, h->stream));
+  h->cur_nseg = 0;
+  const float half_main = (float)(std::max(h->cfg.resx, h->cfg.resy) / 2.0);
+  const int saveN = h->N; h->N = NB;     // loss partial count follows the pre-train batch
+  size_t s = 0;
+  for (int it = 0; it < pretrain_iters && rc == 0; ++it)
+    for (int f = 0; f < F && rc == 0; ++f, ++s) {
+      PrePrepArgs p{};
+      p.ys = d_ys ? d_ys + s * NB : nullptr; p.xs = d_xs ? d_xs + s * NB : nullptr;
+      p.seed = seed; p.iter = (uint32_t)s; p.N = NB; p.resx = h->cfg.resx; p.resy = h->cfg.resy;
+      p.half_main = half_main; p.t = (float)((double)f / (F / 2.0) - 1.0);
+      p.coords = h->coords; p.x0_tile = h->x0_tile;
+      if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
+      FwdArgs fa = fwd_args(h, M, h->coords, M.out_buf, NT, true);
+      if (af_launch_fwd(AF_NET_MAP1, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd"); break; }
+      PreLossArgs l{h->coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
+      if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
+      rc = step_tail(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * 8, false, NT, 0, 0);
+    }
+  h->N = saveN;
+  hipError_t e = hipStreamSynchronize(h->stream);
+  drain_timers(h);
+  if (d_ys) { (void)hipFree(d_ys); (void)hipFree(d_xs); }
+  if (rc) return rc;
+  if (e != hipSuccess) return h->fail(AF_EHIP, "af_pretrain sync", e);
+  if (losses_out) {
+    std::vector<float> tmp(steps * 8);
+    HCHK(hipMemcpy(tmp.data(), h->loss_log, steps * 32, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < steps; ++i) losses_out[i] = tmp[i * 8] / (float)NB;
+  }
+  std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
+  return AF_OK;
+}
+
+int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* inds, uint64_t seed, float* losses_out) {
+  if (!h) return AF_EINVAL;
+  if (!h->have_video) return h->fail(AF_ESTATE, "af_train_steps: no video uploaded");
+  if (n_iters < 0 || first_iter < 0) return h->fail(AF_EINVAL, "af_train_steps: arguments");
+  if (n_iters == 0) return AF_OK;
+  HCHK(hipSetDevice(h->device));
+  const af_config& c = h->cfg;
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
+  const int N = h->N;
+  int rc = ensure_loss_log(h, n_iters); if (rc) return rc;
+  int64_t* d_inds = nullptr;
+  if (inds) {
+    HCHK(dalloc(&d_inds, (size_t)n_iters * N));
+    HCHK(hipMemcpy(d_inds, inds, (size_t)n_iters * N * 8, hipMemcpyHostToDevice));
+  }
+  HCHK(hipMemsetAsync(h->counts, 0, 8, h->stream));
+  const int L = std::max(c.resx, c.resy);
+  const int NT_atlas = tiles_of(3 * N);
+  for (int k = 0; k < n_iters && rc == 0; ++k) {
+    const int i = first_iter + k;
+    const bool glob = c.include_global_rigidity_loss && i <= c.stop_global_rigidity;
+    const int nseg = glob ? 9 : 7;
+    Sched& sc = h->sched[glob ? 0 : 1];
+    const int NT_map = tiles_of(nseg * N);
+    if (nseg != h->cur_nseg) {   // pad rows of the last tile must carry zero gradient
+      if (hipMemsetAsync(M.dout, 0, (size_t)M.nt_cap * 32 * 16, h->stream) != hipSuccess) { rc = h->fail(AF_EHIP, "memset dout"); break; }
+      h->cur_nseg = nseg;
+    }
+    {
+      Timer t(h, 0);
+      PrepArgs p{};
+      p.table = h->table; p.inds = d_inds ? d_inds + (size_t)k * N : nullptr; p.seed = seed; p.iter = (uint32_t)i;
+      p.N = N; p.resx = c.resx; p.resy = c.resy; p.F = c.number_of_frames;
+      p.half_main = (float)(L / 2.0); p.half_grad = (float)(c.resx / 2.0); p.half_frames = (float)(c.number_of_frames / 2.0);
+      p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
+      p.coords = h->coords; p.x0_tile = h->x0_tile; p.samples = h->samples; p.counts = h->counts;
+      if (af_launch_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "prep"); break; }
+    }
+    { Timer t(h, 1); FwdArgs fa = fwd_args(h, M, h->coords, M.out_buf, NT_map, true);
+      if (af_launch_fwd(AF_NET_MAP1, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd map"); break; } }
+    { Timer t(h, 2); FwdArgs fa = fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true);
+      if (af_launch_fwd(AF_NET_ATLAS, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd atlas"); break; } }
+    {
+      Timer t(h, 3);
+      LossArgs l{};
+      l.samples = h->samples; l.out_map = M.out_buf; l.out_atlas = A.out_buf; l.dout_map = M.dout; l.dout_atlas = A.dout;
+      l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
+      l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount; l.d_global = c.global_rigidity_derivative_amount_fg;
+      l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
+      l.c_grig = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_flow = c.optical_flow_coeff;
+      if (af_launch_loss_single(&l, h->stream)) { rc = h->fail(AF_EHIP, "loss"); break; }
+    }
+    h->adam_step += 1;
+    rc = step_tail(h, sc, h->adam_m, h->adam_v, h->adam_step, h->loss_log + (size_t)k * 8, true, NT_map, NT_atlas, 3 * N);
+  }
+  hipError_t e = hipStreamSynchronize(h->stream);
+  drain_timers(h);
+  if (d_inds) (void)hipFree(d_inds);
+  if (rc) return rc;
+  if (e != hipSuccess) return h->fail(AF_EHIP, "af_train_steps sync", e);
+  std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
+  if (losses_out) {
+    std::vector<float> tmp((size_t)n_iters * 8);
+    HCHK(hipMemcpy(tmp.data(), h->loss_log, (size_t)n_iters * 32, hipMemcpyDeviceToHost));
+    bool nan = false;
+    for (int k = 0; k < n_iters; ++k) {
+      const int i = first_iter + k;
+      const bool glob = c.include_global_rigidity_loss && i <= c.stop_global_rigidity;
+      const float* s = &tmp[(size_t)k * 8]; float* o = losses_out + (size_t)k * 8;
+      const float invN = 1.f / (float)N;
+      o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = glob ? s[3] * invN : 0.f;
+      // mean over an empty set is NaN in the reference (loss_utils.py:317-320)
+      o[4] = 0.5f * (s[5] / s[7]) + 0.5f * (s[4] / s[6]);
+      o[5] = c.rigidity_coeff * o[2] + (glob ? c.global_rigidity_coeff_fg * o[3] : 0.f) + c.rgb_coeff * o[0] + c.optical_flow_coeff * o[4] + c.gradient_loss_coeff * o[1];
+      o[6] = s[6]; o[7] = s[7];
+      if (!(o[5] == o[5])) nan = true;
+    }
+    if (nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss (a batch without valid flow pixels, as in the reference, or divergence)");
+  }
+  return AF_OK;
+}
+
+int af_step_work(const af_handle* h, int iter, int64_t* rows_map, int64_t* rows_atlas, double* flops) {
+  if (!h) return AF_EINVAL;
+  const bool glob = h->cfg.include_global_rigidity_loss && iter <= h->cfg.stop_global_rigidity;
+  const int64_t rm = (int64_t)(glob ? 9 : 7) * h->N, ra = (int64_t)3 * h->N;
+  if (rows_map) *rows_map = rm;
+  if (rows_atlas) *rows_atlas = ra;
+  if (flops) *flops = (double)rm * 1579008.0 + (double)ra * 2466784.0;   // BASELINE.md §3 per-row fwd+bwd FLOPs
+  return AF_OK;
+}
+
+static int ensure_render(af_handle* h, int rows) {
+  if (rows <= h->render_rows_cap) return 0;
+  (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
+  h->r_coords = h->r_uv = h->r_t = h->r_rgb = nullptr; h->r_sse = nullptr; h->render_rows_cap = 0;
+  const size_t rp = (size_t)tiles_of(rows) * 32;
+  HCHK(dalloc(&h->r_coords, rp * 4)); HCHK(dalloc(&h->r_uv, rp * 4)); HCHK(dalloc(&h->r_t, rp * 4));
+  HCHK(dalloc(&h->r_rgb, rp * 3)); HCHK(dalloc(&h->r_sse, (rp + 255) / 256));
+  h->render_rows_cap = rows;
+  return 0;
+}
+
+int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* out) {
+  if (!h || !in || !out || rows <= 0) return AF_EINVAL;
+  if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
+  HCHK(hipSetDevice(h->device));
+  int rc = ensure_render(h, rows); if (rc) return rc;
+  const int NT = tiles_of(rows);
+  HCHK(hipMemsetAsync(h->r_coords, 0, (size_t)NT * 32 * 16, h->stream));
+  HCHK(hipMemcpyAsync(h->r_coords, in, (size_t)rows * 16, hipMemcpyHostToDevice, h->stream));
+  FwdArgs fa = fwd_args(h, h->nets[net], h->r_coords, h->r_uv, NT, false);
+  if (h->nets[net].in_kind != AF_IN_XYT) { fa.in_scale = 1.f; fa.in_shift0 = 0.f; fa.in_shift1 = 0.f; }
+  LCHK(af_launch_fwd(net, 0, &fa, h->stream));
+  HCHK(hipMemcpyAsync(out, h->r_uv, (size_t)rows * 16, hipMemcpyDeviceToHost, h->stream));
+  HCHK(hipStreamSynchronize(h->stream));
+  return AF_OK;
+}
+
+int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out) {
+  if (!h) return AF_EINVAL;
+  if (frame < 0 || frame >= h->cfg.number_of_frames) return h->fail(AF_EINVAL, "af_render_frame: frame index");
+  if (!h->have_video) return h->fail(AF_ESTATE, "af_render_frame: no video uploaded");
+  HCHK(hipSetDevice(h->device));
+  const int npix = h->cfg.resx * h->cfg.resy;
+  int rc = ensure_render(h, npix); if (rc) return rc;
+  const int NT = tiles_of(npix), F = h->cfg.number_of_frames;
+  const float half_main = (float)(std::max(h->cfg.resx, h->cfg.resy) / 2.0);
+  const float t = (float)((double)frame / (F / 2.0) - 1.0);     // evaluate.py:656 computes t in Python floats
+  LCHK(af_launch_frame_coords(h->r_coords, h->cfg.resx, h->cfg.resy, half_main, t, NT * 32, h->stream));
+  FwdArgs fm = fwd_args(h, h->nets[AF_NET_MAP1], h->r_coords, h->r_uv, NT, false);
+  LCHK(af_launch_fwd(AF_NET_MAP1, 0, &fm, h->stream));
+  FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false);
+  LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
+  LCHK(af_launch_frame_finish(h->r_t, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
+  const int nblk = (npix + 255) / 256;
+  std::vector<double> part(nblk);
+  HCHK(hipMemcpyAsync(part.data(), h->r_sse, (size_t)nblk * 8, hipMemcpyDeviceToHost, h->stream));
+  if (rgb_out) HCHK(hipMemcpyAsync(rgb_out, h->r_rgb, (size_t)npix * 12, hipMemcpyDeviceToHost, h->stream));
+  HCHK(hipStreamSynchronize(h->stream));
+  double sse = 0; for (double v : part) sse += v;
+  h->frame_sse[frame] = sse; h->frame_sse_valid[frame] = 1;
+  if (sse_out) *sse_out = sse;
+  return AF_OK;
+}
+
+int af_psnr(af_handle* h, double* mean_psnr, double* per_frame) {
+  if (!h) return AF_EINVAL;
+  const int F = h->cfg.number_of_frames; const double cnt = (double)h->cfg.resx * h->cfg.resy * 3.0;
+  double acc = 0;
+  for (int f = 0; f < F; ++f) {
+    if (!h->frame_sse_valid[f]) { int rc = af_render_frame(h, f, nullptr, nullptr); if (rc) return rc; }
+    const double mse = h->frame_sse[f] / cnt;
+    const double p = 10.0 * log10(1.0 / mse);
+    if (per_frame) per_frame[f] = p;
+    acc += p;
+  }
+  if (mean_psnr) *mean_psnr = acc / F;
+  return AF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+/* atlasfit.h — C ABI of libatlasfit.so: the MI355X-native (gfx950) implementation of the stage-1
+ * neural-atlas optimisation loop of All-In-One-Deflicker.
+ *
+ * The reference has no plugin/operator API for this path; its seams are the stage-1 script and the
+ * Python objects it drives.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference repository root).  A handle owns ONE video on ONE device with ONE
+ * stream (reference: one process per GPU via CUDA_VISIBLE_DEVICES, src/stage1_neural_atlas.py:267-268).
+ *
+ * Conventions: every function returns 0 on success and a negative af_status on failure (message via
+ * af_last_error); nothing throws across the boundary; host buffers are borrowed for the duration of
+ * the call; the handle owns all device memory.  All tensors are fp32 unless stated.
+ */
+#ifndef ATLASFIT_H
+#define ATLASFIT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct af_handle af_handle;
+
+enum af_status { AF_OK = 0, AF_EINVAL = -1, AF_EHIP = -2, AF_ENOMEM = -3, AF_ENAN = -4, AF_ESTATE = -5 };
+enum af_net { AF_MAPPING1 = 0, AF_ATLAS = 1, AF_MAPPING2 = 2, AF_ALPHA = 3 };
+
+/* Mirrors the keys of src/config/config_flow_100.json that the loop reads
+ * (src/stage1_neural_atlas.py:28-90) plus the sizes main() derives (resx, resy, number_of_frames). */
+typedef struct af_config {
+  int32_t resx, resy, number_of_frames;          /* stage1_neural_atlas.py:31-38,108 */
+  int32_t samples_batch;                         /* config :7 */
+  int32_t number_of_channels_mapping1, number_of_layers_mapping1;   /* config :24-25  (256, 6) */
+  int32_t number_of_channels_atlas, number_of_layers_atlas;         /* config :19-20  (256, 8) */
+  int32_t positional_encoding_num_atlas;         /* config :31 (10) */
+  int32_t use_positional_encoding_mapping1;      /* config :32 (false; true is not built) */
+  int32_t derivative_amount;                     /* config :10 */
+  int32_t include_global_rigidity_loss;          /* config :39 */
+  int32_t global_rigidity_derivative_amount_fg;  /* config :40 */
+  int32_t stop_global_rigidity;                  /* config :44 */
+  int32_t use_gradient_loss;                     /* config :29 (must be true) */
+  float rgb_coeff, gradient_loss_coeff, rigidity_coeff, optical_flow_coeff;   /* config :11,28,12,8 */
+  float global_rigidity_coeff_fg;                /* config :42 */
+  float uv_mapping_scale;                        /* config :13 */
+  float lr;                                      /* 1e-4, hard-coded at stage1_neural_atlas.py:134 */
+  int32_t pretrain_batch;                        /* 10000, hard-coded at unwrap_utils.py:182-183 */
+  int32_t reserved[8];
+} af_config;
+
+/* Replaces model construction + optimizer construction (stage1_neural_atlas.py:112-134).  Parameters
+ * start at zero; load them with af_set_params. */
+int af_create(const af_config* cfg, int device_ordinal, af_handle** out);
+void af_destroy(af_handle* h);
+const char* af_last_error(const af_handle* h);   /* h may be NULL: message of the last failed af_create */
+
+/* Replaces the tensors returned by load_input_data_single (src/models/stage_1/unwrap_utils.py:105-163),
+ * the dx/dy construction (:132-133) and get_tuples (:166-173; the index table is arithmetic here).
+ * Layouts are the reference's: frames (resy,resx,3,F); flows (resy,resx,2,F[,1]); masks (resy,resx,F[,1]);
+ * mask_fg (resy,resx,F) or NULL.  on_device != 0: the pointers are device pointers on this handle's GPU. */
+int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, const float* flow_bwd,
+                    const float* mask_fwd, const float* mask_bwd, const float* mask_fg, int on_device);
+
+/* IMLP.state_dict() order: hidden.0.weight (out,in) row-major, hidden.0.bias, hidden.1.weight, ...
+ * (src/models/stage_1/implicit_neural_networks.py:37-52). */
+size_t af_param_count(const af_handle* h, int net);
+int af_set_params(af_handle* h, int net, const float* flat, size_t n);
+int af_get_params(af_handle* h, int net, float* flat, size_t n);
+/* torch.optim.Adam state of optimizer_all (exp_avg, exp_avg_sq, step) for one net's parameters. */
+int af_get_adam_state(af_handle* h, int net, float* exp_avg, float* exp_avg_sq, int64_t* step);
+int af_set_adam_state(af_handle* h, int net, const float* exp_avg, const float* exp_avg_sq, int64_t step);
+
+/* pre_train_mapping (src/models/stage_1/unwrap_utils.py:176-198): pretrain_iters x number_of_frames Adam
+ * steps (own optimizer, lr 1e-4) on `net` (AF_MAPPING1/2).  ys/xs: [pretrain_iters*F][pretrain_batch]
+ * row / column draws in the reference's order (i_s then j_s), or NULL for the device sampler(seed).
+ * losses_out: [pretrain_iters*F] mean loss per step, or NULL. */
+int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, const int64_t* xs,
+                uint64_t seed, float* losses_out);
+
+/* The loop body (src/stage1_neural_atlas.py:151-231) for iterations first_iter .. first_iter+n_iters-1.
+ * inds: [n_iters][samples_batch] values of inds_foreground (:159-160), or NULL for the device sampler.
+ * losses_out: [n_iters][8] = rgb, gradient, rigidity, global rigidity, flow, total, #valid fwd, #valid bwd
+ * (the un-weighted terms of :186-218 and the weighted sum of :220-227), or NULL. */
+int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* inds, uint64_t seed,
+                   float* losses_out);
+
+/* Forward-only reconstruction of one frame (src/models/stage_1/evaluate.py:640-661):
+ * rgb_out (resy,resx,3) host buffer or NULL; sse_out: sum of squared error vs the input frame (fp64). */
+int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out);
+/* Mean over frames of skimage PSNR(data_range=1) (evaluate.py:740-743,775); per_frame[F] optional. */
+int af_psnr(af_handle* h, double* mean_psnr, double* per_frame);
+
+int af_sync(af_handle* h);
+
+/* ---- test / measurement hooks (not part of the reference surface) --------------------------------- */
+/* Run one net forward on caller rows: in [rows][4] host -> out [rows][4] host. */
+int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* out);
+/* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
+int af_set_debug(af_handle* h, int enable);
+int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);
+/* Time the most recent kernels: returns accumulated HIP-event milliseconds per kernel class since the last
+ * reset: [0]=prep [1]=fwd_map [2]=fwd_atlas [3]=loss [4]=bwd_atlas [5]=bwd_map [6]=dw [7]=adam; counts[8]. */
+int af_set_timing(af_handle* h, int enable);
+int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset);
+/* Algorithmic work of ONE train step at the given iteration (rows per net, FLOPs): see DESIGN.md. */
+int af_step_work(const af_handle* h, int iter, int64_t* rows_map, int64_t* rows_atlas, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    g = dict(np.load(os.path.join(GOLDEN, "single_small.npz"), allow_pickle=False))
+    s = dict(np.load(os.path.join(GOLDEN, "single_small_start.npz")))
+    g.update(s)
+    g["config"] = {str(k): float(v) for k, v in zip(g["config_keys"], g["config_vals"])}
+    for k in ("samples_batch", "derivative_amount", "number_of_channels_atlas", "number_of_layers_atlas",
+              "number_of_channels_mapping1", "number_of_layers_mapping1", "positional_encoding_num_atlas",
+              "number_of_positional_encoding_mapping1", "global_rigidity_derivative_amount_fg", "stop_global_rigidity"):
+        g["config"][k] = int(g["config"][k])
+    for k in ("use_gradient_loss", "use_positional_encoding_mapping1", "include_global_rigidity_loss"):
+        g["config"][k] = bool(g["config"][k])
+    return g
+
+
+@pytest.fixture(scope="session")
+def small_video(golden):
+    from oracle import atlas_oracle as O
+    v = O.synthetic_video(int(golden["resx"]), int(golden["resy"]), int(golden["nframes"]), seed=int(golden["video_seed"]))
+    assert abs(float(v.video_frames.double().sum()) - float(golden["video_checksum"])) < 1e-6
+    assert float(v.optical_flows_mask.sum()) == float(golden["mask_checksum"])
+    return v
