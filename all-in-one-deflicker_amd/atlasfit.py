@@ -311,8 +311,8 @@ class AtlasFit:
         self._chk(self.lib.af_get_last_grads(self.h, net, _ptr(g), g.size))
         return g
 
-    def set_timing(self, on=True):
-        self._chk(self.lib.af_set_timing(self.h, int(on)))
+    def set_timing(self, mask=0xFF):
+        self._chk(self.lib.af_set_timing(self.h, int(mask) if not isinstance(mask, bool) else (0xFF if mask else 0)))
 
     def timing(self, reset=True):
         ms = np.zeros(8, np.float64); cnt = np.zeros(8, np.int64)

@@ -83,7 +83,7 @@ struct af_handle {
   // render
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
-  bool debug = false, timing = false;
+  bool debug = false; unsigned timing = 0;
   std::vector<TimedEv> evs; double t_ms[8] = {0}; long long t_cnt[8] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -209,25 +209,33 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses, float
   const int nj = (int)sc.jobs.size();
   auto tile_cost = [&](int j) { int To, Ti; return (double)shape_tiles(sc.jobs[j].shape, To, Ti) + 20.0; };
   const double seg_cost = 60.0;
-  double total = 0;
-  for (int j = 0; j < nj; ++j) total += tile_cost(j) * job_nt[j] + seg_cost;
-  int nwg = (int)std::min<double>(h->ncu, std::max(1.0, total / (16.0 * 276.0)));
+  double work = 0;
+  for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
+  int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (16.0 * 276.0)));
+  // Cut the job sequence (largest jobs first) into nwg pieces of equal cost.  Boundaries are placed on the
+  // CUMULATIVE cost line (rounding to the nearest tile), so rounding never accumulates onto the last workgroup.
   std::vector<int> order(nj);
   for (int j = 0; j < nj; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tile_cost(a) * job_nt[a] > tile_cost(b) * job_nt[b]; });
   std::vector<int> nslots(nj, 0);
   std::vector<std::vector<DwSeg>> wg(nwg);
+  const double total = work + seg_cost * (nj + nwg);
   const double target = total / nwg;
-  int w = 0; double fill = 0;
+  int w = 0; double cum = 0;
   for (int oi = 0; oi < nj; ++oi) {
     const int j = order[oi]; int t = 0; const double tc = tile_cost(j);
     while (t < job_nt[j]) {
-      if (w < nwg - 1 && (fill + seg_cost + tc > target || (int)wg[w].size() >= DW_MAXSEG - 1)) { ++w; fill = 0; }
-      double room = target - fill - seg_cost;
-      int take = w == nwg - 1 ? job_nt[j] - t : (int)std::max(1.0, floor(room / tc));
-      take = std::min(take, job_nt[j] - t);
+      const double bound = (w + 1) * target;
+      int take;
+      if (w == nwg - 1) take = job_nt[j] - t;
+      else {
+        take = (int)floor((bound - cum - seg_cost) / tc + 0.5);
+        if (take <= 0 || (int)wg[w].size() >= DW_MAXSEG) { ++w; continue; }
+        take = std::min(take, job_nt[j] - t);
+      }
       wg[w].push_back({j, t, t + take, nslots[j]++});
-      fill += seg_cost + tc * take; t += take;
+      cum += seg_cost + tc * take; t += take;
+      if (w < nwg - 1 && cum >= bound - 0.5 * tc) ++w;
     }
   }
   sc.nwg = nwg;
@@ -299,9 +307,10 @@ BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
 struct Timer {
   af_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr;
   Timer(af_handle* h_, int c) : h(h_), cls(c) {
-    if (h->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+    if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); }
   }
-  ~Timer() { if (h->timing) { hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); } }
+  ~Timer() { if (on()) { (void)hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); } }
+  bool on() const { return (h->timing >> cls) & 1u; }
 };
 
 void drain_timers(af_handle* h) {
@@ -526,7 +535,7 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
 }
 
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
-int af_set_timing(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->timing = enable != 0; return AF_OK; }
+int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFu; return AF_OK; }
 int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset) {
   if (!h) return AF_EINVAL;
   hipSetDevice(h->device); hipStreamSynchronize(h->stream); drain_timers(h);

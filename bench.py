@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py — atlas-fit sampled points/s (stage 1 main loop) on N GPUs of one node.
+
+A "step" is one iteration of the optimisation loop (src/stage1_neural_atlas.py:151-231 of the reference)
+over one batch of samples_batch = 10 000 sampled (x,y,t) points of a synthetic 80-frame 768x432 video
+(BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  The K timed steps are
+centred on iteration 5000 so that half of them carry the global-rigidity rows, like the 10 001-iteration
+schedule the metric is quoted on.  N > 1: one independent video per GPU (weak scaling), RCCL barrier only.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# algorithmic FLOPs per MLP row: forward, dX chain, dW
+FLOP_ROW = {
+    "fwd_map": 526848.0, "bwd_map": 525312.0, "dw_map": 526848.0,
+    "fwd_atlas": 829168.0, "bwd_atlas": 808448.0, "dw_atlas": 829168.0,
+}
+
+
+def synth_video_device(resx, resy, nframes, seed, device):
+    """Seeded synthetic flickering video generated directly in HBM (same construction as SURVEY.md §8d:
+    translating smooth texture, per-frame gain/gamma flicker, exact flows, reference consistency rule)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    nw = 12
+    scale = 2 * 3.141592653589793 * 6 / max(resx, resy)
+    kx = ((torch.rand(nw, 3, generator=g) * 2 - 1) * scale).to(device)
+    ky = ((torch.rand(nw, 3, generator=g) * 2 - 1) * scale).to(device)
+    ph = (torch.rand(nw, 3, generator=g) * 2 * 3.141592653589793).to(device)
+    amp = (torch.rand(nw, 3, generator=g) * 0.7 + 0.3).to(device)
+    gain = torch.rand(nframes, generator=g) * 0.4 + 0.8
+    gamma = torch.rand(nframes, generator=g) * 0.2 + 0.9
+    vx, vy = 1.5, 0.5
+    yy, xx = torch.meshgrid(torch.arange(resy, device=device, dtype=torch.float32),
+                            torch.arange(resx, device=device, dtype=torch.float32), indexing="ij")
+    frames = torch.empty(resy, resx, 3, nframes, device=device)
+    for f in range(nframes):
+        xs, ys = (xx - f * vx)[..., None, None], (yy - f * vy)[..., None, None]
+        tex = (amp.T[None, None] * torch.sin(kx.T[None, None] * xs + ky.T[None, None] * ys + ph.T[None, None])).sum(-1)
+        tex = 0.5 + 0.5 * tex / amp.sum(0)
+        frames[:, :, :, f] = (float(gain[f]) * tex.clamp(1e-3, 1.0) ** float(gamma[f])).clamp(0.0, 1.0)
+    flows = torch.zeros(resy, resx, 2, nframes, device=device)
+    flows_rev = torch.zeros_like(flows)
+    flows[:, :, 0, :-1] = vx; flows[:, :, 1, :-1] = vy
+    flows_rev[:, :, 0, 1:] = -vx; flows_rev[:, :, 1, 1:] = -vy
+    # consistency rule ||f12 + warp(f21)|| < 1 with zero border: invalid where the flow leaves the frame
+    inb_f = ((xx + vx >= 0) & (xx + vx <= resx - 1) & (yy + vy >= 0) & (yy + vy <= resy - 1)).float()
+    inb_b = ((xx - vx >= 0) & (xx - vx <= resx - 1) & (yy - vy >= 0) & (yy - vy <= resy - 1)).float()
+    mask = torch.zeros(resy, resx, nframes, device=device)
+    mask_rev = torch.zeros_like(mask)
+    mask[:, :, :-1] = inb_f[..., None]
+    mask_rev[:, :, 1:] = inb_b[..., None]
+    return frames, flows, flows_rev, mask, mask_rev
+
+
+def init_state_dicts(seed):
+    """torch default nn.Linear init in the reference's construction order (stage1_neural_atlas.py:112-128)."""
+    import torch
+    import aiod_amd
+    torch.manual_seed(seed)
+    sds = {}
+    for net in (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS):
+        sd = {}
+        for i, (o, k) in enumerate(aiod_amd.atlasfit.imlp_shapes(net)):
+            lin = torch.nn.Linear(k, o)
+            sd["hidden.%d.weight" % i] = lin.weight.detach()
+            sd["hidden.%d.bias" % i] = lin.bias.detach()
+        sds[net] = sd
+    return sds
+
+
+def cpu_baseline(resx, resy, nframes, seed, sds, video_dev, budget_s):
+    """The oracle (a PyTorch-CPU restatement of the reference loop) on the host cores, same workload,
+    bounded sample: iterations until ~budget_s seconds (>= 4), half with the global-rigidity term."""
+    import torch
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video_dev]
+    v = O.Video(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None])
+    m, a = O.build_single_atlas_models(cfg, seed=0)
+    m.load_state_dict(sds[aiod_amd.NET_MAPPING1]); a.load_state_dict(sds[aiod_amd.NET_ATLAS])
+    tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    N = cfg["samples_batch"]
+    g = torch.Generator().manual_seed(seed)
+    P = tr.jif_all.shape[1]
+    tr.step(0, torch.randint(P, (N,), generator=g))          # warm-up (not timed)
+    t0 = time.perf_counter(); n = 0
+    while n < 4 or (time.perf_counter() - t0 < budget_s and n < 200):
+        it = 4000 if n % 2 == 0 else 6000                   # alternate: with / without global rigidity
+        tr.step(it, torch.randint(P, (N,), generator=g)); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": N * n / dt, "unit": "sampled points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d loop iterations (N=10000, alternating with/without the global-rigidity term) of the oracle restatement, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--resx", type=int, default=768)
+    ap.add_argument("--resy", type=int, default=432)
+    ap.add_argument("--frames", type=int, default=80)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pretrain-iters", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import aiod_amd
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert args.gpus == world, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    cfg = aiod_amd.default_config(args.resx, args.resy, args.frames)
+    N = cfg.samples_batch
+    af = aiod_amd.AtlasFit(cfg, device=local)
+    video = synth_video_device(args.resx, args.resy, args.frames, seed=rank, device=dev)
+    af.upload_video(*video)
+    sds = init_state_dicts(1234 + rank)
+    af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1])
+    af.load_state_dict(aiod_amd.NET_ATLAS, sds[aiod_amd.NET_ATLAS])
+    if args.pretrain_iters > 0:
+        af.pre_train_mapping(args.pretrain_iters, seed=rank)     # untimed; puts the mapping in a realistic regime
+
+    K, W = args.steps, args.warmup
+    switch = cfg.stop_global_rigidity + 1                           # first iteration without the global term
+    first = max(0, switch - K // 2)
+    classes = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (W untimed steps, all kernel classes timed to find the dominant one)
+    af.set_timing(0xFF)
+    wfirst = max(0, first - W)
+    if W > 0:
+        af.train_steps(wfirst, W, None, seed=rank, return_losses=False)
+    tw = af.timing(reset=True)
+    dom = max(classes, key=lambda c: tw[c][0]) if W > 0 else "dw"
+    af.set_timing(1 << classes.index(dom))                         # events only around the dominant kernel
+
+    # ---- timed region: EXACTLY K steps
+    barrier()
+    t0 = time.perf_counter()
+    af.train_steps(first, K, None, seed=rank, return_losses=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    tk = af.timing(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: algorithmic FLOPs per launch / mean HIP-event duration
+    flops_launch = 0.0
+    for k in range(K):
+        rm, ra, _ = af.step_work(first + k)
+        if dom in ("fwd_map", "bwd_map"):
+            flops_launch += rm * FLOP_ROW[dom]
+        elif dom in ("fwd_atlas", "bwd_atlas"):
+            flops_launch += ra * FLOP_ROW[dom]
+        elif dom == "dw":
+            flops_launch += rm * FLOP_ROW["dw_map"] + ra * FLOP_ROW["dw_atlas"]
+    flops_launch /= K
+    dom_ms = tk[dom][0] / max(tk[dom][1], 1)
+    achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    total_flops = sum(af.step_work(first + k)[2] for k in range(K))
+
+    out = None
+    if rank == 0:
+        value = world * N * K / dt
+        out = {
+            "metric": "atlas-fit sampled points/sec (stage1 main loop)", "value": value, "unit": "sampled points/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
+                                   "timed iterations %d..%d (half with the global-rigidity rows); one video per GPU"
+                                   % (args.frames, args.resx, args.resy, N, first, first + K - 1),
+                       "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": dom_ms, "flops_per_launch": flops_launch,
+                         "whole_step_tflops": total_flops / dt / 1e12, "whole_step_frac": total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.resx, args.resy, args.frames, 0, sds, video, args.cpu_seconds)
+            except Exception as e:   # the baseline is a reported number, never the product
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    af.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

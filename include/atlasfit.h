@@ -97,7 +97,7 @@ int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);
 /* Time the most recent kernels: returns accumulated HIP-event milliseconds per kernel class since the last
  * reset: [0]=prep [1]=fwd_map [2]=fwd_atlas [3]=loss [4]=bwd_atlas [5]=bwd_map [6]=dw [7]=adam; counts[8]. */
-int af_set_timing(af_handle* h, int enable);
+int af_set_timing(af_handle* h, int class_mask);   /* bit i enables HIP-event timing of kernel class i */
 int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset);
 /* Algorithmic work of ONE train step at the given iteration (rows per net, FLOPs): see DESIGN.md. */
 int af_step_work(const af_handle* h, int iter, int64_t* rows_map, int64_t* rows_atlas, double* flops);

