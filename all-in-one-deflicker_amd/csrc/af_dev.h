@@ -51,7 +51,8 @@ struct FwdArgs {
   float* pe_tile;             // [NT][64][32] PE features in T-layout     (train only, PE nets)
   float in_scale, in_shift0, in_shift1;   // PE nets: x = v*scale + (row < split_row ? shift0 : shift1)
   int split_row;
-  int NT;                     // row tiles
+  int tile0;                  // first row tile of this launch
+  int NT;                     // one past the last row tile (also the tile stride of acts/masks)
   int nchunks;
 };
 
@@ -68,6 +69,7 @@ struct BwdArgs {
   float din_scale;
   int split_row;
   int nrows;                  // rows that own an input gradient (pad rows are skipped)
+  int tile0;
   int NT;
   int nchunks;
 };

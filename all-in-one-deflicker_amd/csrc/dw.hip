@@ -17,20 +17,15 @@
 
 #define DW_BUF 65536
 
-// stage `bytes` (multiple of 4096) of a T-layout tile into LDS with the 16-B-slot swizzle
-// physical slot c of feature row f holds logical row-group c ^ ((f>>1)&7)
-AF_DEV void dw_stage(const char* src, int bytes, char* dst, int tid, int wave) {
-  const int nit = bytes >> 12;
-  for (int it = 0; it < nit; ++it) {
-    const int s = it * 256 + tid;
-    const int f = s >> 3, c = s & 7;
-    af_glds16(src + ((f << 3) + (c ^ ((f >> 1) & 7))) * 16, dst + it * 4096 + wave * 1024);
-  }
+// One 4 KB piece (256 lanes x 16 B) of a T-layout tile -> LDS with the 16-B-slot swizzle: physical slot c of
+// feature row f holds logical row-group c ^ ((f>>1)&7).  lane_off = the per-lane swizzled source offset.
+AF_DEV void dw_stage_piece(const char* src, char* dst, int it, int lane_off, int wave) {
+  af_glds16(src + it * 4096 + lane_off, dst + it * 4096 + wave * 1024);
 }
 
-template <int TOW, int TIW>
+template <int TO, int TI, int TOW, int TIW>
 AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
-                       int TO, int TI, int a0, int b0, bool store_w, bool store_db) {
+                       int a0, int b0, bool store_w, bool store_db) {
   const int m = lane & 31, h = lane >> 5;
   f32x16 acc[TOW][TIW];
   float dbacc[TOW];
@@ -42,13 +37,19 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   }
-  const int a_bytes = TO * 4096, b_bytes = TI * 4096;
+  constexpr int a_bytes = TO * 4096, b_bytes = TI * 4096;
+  constexpr int NPIECE = TO + TI, PER_G = (NPIECE + 3) / 4;
   const char* Ab = (const char*)jb.A;
   const char* Bb = (const char*)jb.B;
   const size_t a_ts = (size_t)jb.a_stride * 4, b_ts = (size_t)jb.b_stride * 4;
+  const int lane_off = ((((tid >> 3) << 3) + ((tid & 7) ^ ((tid >> 4) & 7))) << 4);
 
-  dw_stage(Ab + sg.t0 * a_ts, a_bytes, smem, tid, wave);
-  dw_stage(Bb + sg.t0 * b_ts, b_bytes, smem + a_bytes, tid, wave);
+  auto stage_piece = [&](int t, char* buf, int i) {     // piece i of tile t: first TO pieces = A, rest = B
+    if (i < TO) dw_stage_piece(Ab + t * a_ts, buf, i, lane_off, wave);
+    else        dw_stage_piece(Bb + t * b_ts, buf + a_bytes, i - TO, lane_off, wave);
+  };
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) stage_piece(sg.t0, smem, i);
 
   const int swz = (m >> 1) & 7;
   int goff[4];
@@ -59,35 +60,42 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
     af_wait_vm0();
     __syncthreads();
     const int cur = (t - sg.t0) & 1;
-    if (t + 1 < sg.t1) {
-      char* nb = smem + (cur ^ 1) * DW_BUF;
-      dw_stage(Ab + (t + 1) * a_ts, a_bytes, nb, tid, wave);
-      dw_stage(Bb + (t + 1) * b_ts, b_bytes, nb + a_bytes, tid, wave);
-    }
+    const int tn = t + 1 < sg.t1 ? t + 1 : t;           // last tile: harmless re-stage into the idle buffer
+    char* nb = smem + (cur ^ 1) * DW_BUF;
     const char* abuf = smem + cur * DW_BUF + a0 * 4096;
     const char* bbuf = smem + cur * DW_BUF + a_bytes + b0 * 4096;
+    f32x4 af[2][TOW], bf[2][TIW];
+#pragma unroll
+    for (int x = 0; x < TOW; ++x) af[0][x] = *(const f32x4*)(abuf + x * 4096 + goff[0]);
+#pragma unroll
+    for (int y = 0; y < TIW; ++y) bf[0][y] = *(const f32x4*)(bbuf + y * 4096 + goff[0]);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 af[TOW], bf[TIW];
+      if (g + 1 < 4) {
 #pragma unroll
-      for (int x = 0; x < TOW; ++x) af[x] = *(const f32x4*)(abuf + x * 4096 + goff[g]);
+        for (int x = 0; x < TOW; ++x) af[(g + 1) & 1][x] = *(const f32x4*)(abuf + x * 4096 + goff[g + 1]);
 #pragma unroll
-      for (int y = 0; y < TIW; ++y) bf[y] = *(const f32x4*)(bbuf + y * 4096 + goff[g]);
+        for (int y = 0; y < TIW; ++y) bf[(g + 1) & 1][y] = *(const f32x4*)(bbuf + y * 4096 + goff[g + 1]);
+      }
 #pragma unroll
-      for (int x = 0; x < TOW; ++x) dbacc[x] += (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
+      for (int i = g * PER_G; i < (g + 1) * PER_G && i < NPIECE; ++i) stage_piece(tn, nb, i);   // next tile, in this group's MFMA shadow
+#pragma unroll
+      for (int x = 0; x < TOW; ++x) dbacc[x] += (af[g & 1][x][0] + af[g & 1][x][1]) + (af[g & 1][x][2] + af[g & 1][x][3]);
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int x = 0; x < TOW; ++x)
 #pragma unroll
           for (int y = 0; y < TIW; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][p], bf[y][p], acc[x][y], 0, 0, 0);
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][x][p], bf[g & 1][y][p], acc[x][y], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();   // everyone done reading LDS before the next segment restages buffer 0
+  af_wait_vm0();
+  __syncthreads();   // everyone done reading LDS (and the trailing re-stage landed) before the next segment restages
 
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
-  const int pld = TI * 32;
+  constexpr int pld = TI * 32;
   const auto rblk = af_rsrc(blk, jb.part_blk * 4);
   if (store_w) {
     const int voff = ((a0 * 32 + 4 * h) * pld + b0 * 32 + m) * 4;
@@ -117,11 +125,11 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
     if (sg.job < 0) break;
     const DwJob jb = a.jobs[sg.job];
     switch (jb.shape) {
-      case DW_8x8: dw_segment<2, 8>(jb, sg, a.partial, smem, tid, wave, lane, 8, 8, 2 * wave, 0, true, true); break;
-      case DW_8x2: dw_segment<2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 8, 2, 2 * wave, 0, true, true); break;
-      case DW_8x1: dw_segment<2, 1>(jb, sg, a.partial, smem, tid, wave, lane, 8, 1, 2 * wave, 0, true, true); break;
-      case DW_1x8: dw_segment<1, 2>(jb, sg, a.partial, smem, tid, wave, lane, 1, 8, 0, 2 * wave, true, wave == 0); break;
-      case DW_1x2: dw_segment<1, 1>(jb, sg, a.partial, smem, tid, wave, lane, 1, 2, 0, wave & 1, wave < 2, wave == 0); break;
+      case DW_8x8: dw_segment<8, 8, 2, 8>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_8x2: dw_segment<8, 2, 2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_8x1: dw_segment<8, 1, 2, 1>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_1x8: dw_segment<1, 8, 1, 2>(jb, sg, a.partial, smem, tid, wave, lane, 0, 2 * wave, true, wave == 0); break;
+      case DW_1x2: dw_segment<1, 2, 1, 1>(jb, sg, a.partial, smem, tid, wave, lane, 0, wave & 1, wave < 2, wave == 0); break;
       default: break;
     }
   }

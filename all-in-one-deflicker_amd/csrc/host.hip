@@ -385,6 +385,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
   size_t fc = 0, bc = 0, biasc = 0, pc = 0;
   for (NetDesc& n : h->nets) if (n.used) { n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc); }
+  fc += AF_CHUNK_MAX / 4; bc += AF_CHUNK_MAX / 4;   // every LDS stage copies a full 64 KB buffer: keep the over-read in bounds
   h->total_params = pc; h->img_f_floats = fc; h->img_b_floats = bc; h->bias_floats = biasc;
   CCHK(dalloc(&h->params, pc)); CCHK(dalloc(&h->adam_m, pc)); CCHK(dalloc(&h->adam_v, pc));
   CCHK(dalloc(&h->pre_m, pc)); CCHK(dalloc(&h->pre_v, pc)); CCHK(dalloc(&h->grads, pc));

@@ -11,7 +11,13 @@
 // registers (see "C-layout" in af_dev.h).  The four waves of a workgroup share the weight stream, which is
 // double-buffered in LDS in 64 KB chunks by global_load_lds (one barrier per chunk, 16 K MFMA cycles apart).
 // LDS: 2 x 64 KB.  Registers: 128 (activations) + 128 (accumulators) + 64 (A fragments) -> 1 wave / SIMD.
+#include <utility>
+
 #include "af_dev.h"
+
+#ifndef AF_ABL
+#define AF_ABL 0   // bit0 no tile stores, bit1 no LDS-DMA, bit2 no barriers, bit3 no LDS fragment reads, bit4 no sched_barrier
+#endif
 
 struct NsMap1  { static constexpr int NL = 6, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsMap2  { static constexpr int NL = 4, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
@@ -19,42 +25,71 @@ struct NsAtlas { static constexpr int NL = 8, IN = AF_IN_PE2, K0G = 5, PEG = 5, 
 struct NsAlpha { static constexpr int NL = 8, IN = AF_IN_PE3, K0G = 4, PEG = 4, OUT = 1; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 
 // acc[T] += A(image in LDS) * b[B0 + 4*g + p]  for NG k-groups; a_lds already includes the lane offset
-// (h*MPAD + j)*16.  NP < 4 skips reduction indices that are structurally zero.
-template <int MT, int NG, int B0, int NP, int NB>
-AF_DEV void mm_block(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds) {
+// (h*MPAD + j)*16.  NP < 4 skips reduction indices that are structurally zero.  hook(g) is called once per
+// k-group right after that group's A-fragment reads were issued: work placed there (LDS-DMA issue of the
+// next weight chunk, stores of the previous layer's activations) runs in the shadow of the group's MFMAs
+// instead of in front of an empty matrix pipe.
+template <int G> struct GIdx { static constexpr int value = G; };
+
+template <int MT, int NG, int B0, int NP, int NB, class Hook, int... Gs>
+AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook& hook, std::integer_sequence<int, Gs...>) {
   constexpr int MPAD = MT * 32;
   f32x4 a[2][MT];
 #pragma unroll
   for (int T = 0; T < MT; ++T) a[0][T] = *(const f32x4*)(a_lds + T * 32 * 16);
+  if constexpr (AF_ABL & 8) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) {
+    for (int T = 0; T < MT; ++T) a[1][T] = a[0][T];
+  }
+  auto step = [&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    if constexpr (g + 1 < NG && !(AF_ABL & 8)) {
 #pragma unroll
       for (int T = 0; T < MT; ++T) a[(g + 1) & 1][T] = *(const f32x4*)(a_lds + ((g + 1) * 2 * MPAD + 32 * T) * 16);
     }
+    hook(gi);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int T = 0; T < MT; ++T)
         acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][T][p], b[B0 + g * 4 + p], acc[T], 0, 0, 0);
     }
-  }
+    if constexpr (!(AF_ABL & 16)) __builtin_amdgcn_sched_barrier(0);     // keep each group's DMA / stores inside its own MFMA shadow
+  };
+  (step(GIdx<Gs>{}), ...);
+}
+template <int MT, int NG, int B0, int NP, int NB, class Hook>
+AF_DEV void mm_block(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook&& hook) {
+  mm_block_impl<MT, NG, B0, NP>(acc, b, a_lds, hook, std::make_integer_sequence<int, NG>{});
 }
 
+// Double-buffered LDS stream of weight chunks shared by the four waves of the workgroup.  Every stage moves
+// a full 64 KB buffer (16 x 1 KB per wave) whatever the chunk's real size — the image buffers are padded so
+// the over-read stays in bounds — which keeps the issue sites branch-free: two LDS-DMA instructions per
+// k-group ride in the shadow of that group's 32 MFMAs.
 struct ChunkStream {
   const char* img; const AfChunk* tab; char* smem; int tid, wave, cidx, n;
-  AF_DEV void issue(int c) {
-    const AfChunk d = tab[c];
-    af_stage_chunk(img + d.off, d.bytes, smem + (c & 1) * AF_CHUNK_MAX, tid, wave);
+  const char* p_src; char* p_dst; int p_it;            // chunk being staged (issued incrementally)
+  AF_DEV void begin_stage(int c) {
+    const AfChunk d = tab[c < n ? c : 0];              // past the end: harmless re-read of chunk 0 into the idle buffer
+    p_src = img + d.off + tid * 16; p_dst = smem + (c & 1) * AF_CHUNK_MAX + wave * 1024;
+    p_it = 0;
   }
-  // Wait until chunk `cidx` has landed for every wave, and every wave is done with chunk cidx-1;
-  // start fetching chunk cidx+1 into the buffer chunk cidx-1 used; return the LDS base of chunk cidx.
+  AF_DEV void issue2() {
+    if constexpr (AF_ABL & 2) { p_it += 2; return; }
+    af_glds16(p_src + p_it * 4096, p_dst + p_it * 4096);
+    af_glds16(p_src + p_it * 4096 + 4096, p_dst + p_it * 4096 + 4096);
+    p_it += 2;
+  }
+  AF_DEV void start() { cidx = 0; begin_stage(0); }
+  // Make chunk `cidx` visible to every wave (and know every wave is done with chunk cidx-1), then arm the
+  // staging of chunk cidx+1 into the buffer chunk cidx-1 used.  Returns the LDS base of chunk cidx.
   AF_DEV const char* next() {
-    af_wait_vm0();
-    __syncthreads();
+    while (p_it < 16) issue2();
+    if constexpr (!(AF_ABL & 4)) { af_wait_vm0(); __syncthreads(); }
     const int cur = cidx;
-    if (cur + 1 < n) issue(cur + 1);
     cidx = cur + 1;
+    begin_stage(cidx);
     return smem + (cur & 1) * AF_CHUNK_MAX;
   }
 };
@@ -70,16 +105,21 @@ AF_DEV void init_bias(f32x16 (&acc)[8], __amdgpu_buffer_rsrc_t rb, int layer, in
   }
 }
 
-// Store a C-layout block (reg = 16T+4q+p <-> feature 32T+8q+4h+p) as a T-layout tile [256][32].
-AF_DEV void store_tile(const float (&v)[128], float* tile_base, int j, int h) {
-  const auto r = af_rsrc(tile_base, AF_TILE_F * 4);
-  const int voff = (4 * h * 32 + j) * 4;
+// Store 1/8 (feature tile T) of a C-layout block (reg = 16T+4q+p <-> feature 32T+8q+4h+p) into a T-layout
+// tile [256][32].
+template <int T>
+AF_DEV void store_tile_part(const float (&v)[128], __amdgpu_buffer_rsrc_t r, int voff) {
 #pragma unroll
-  for (int T = 0; T < 8; ++T)
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-      af_bs32(v[T * 16 + rr], r, voff, (32 * T + (rr & 3) + 8 * (rr >> 2)) * 128);
+  for (int rr = 0; rr < 16; ++rr) af_bs32(v[T * 16 + rr], r, voff, (32 * T + (rr & 3) + 8 * (rr >> 2)) * 128);
 }
+
+// Deferred stores of one 32x256 block: one feature tile per k-group of the following GEMM block.
+// A dead wave (tile past the end) carries a zero-length buffer descriptor: its stores are dropped by the
+// hardware bounds check, so the store sites need no branch.
+struct TileStore {
+  __amdgpu_buffer_rsrc_t r; int voff;
+  template <int G> AF_DEV void part(const float (&v)[128]) { if constexpr (G < 8 && !(AF_ABL & 1)) store_tile_part<G>(v, r, voff); }
+};
 
 template <class NS, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
@@ -87,13 +127,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-  int tile = blockIdx.x * 4 + wave;
+  int tile = a.tile0 + blockIdx.x * 4 + wave;
   const bool live = tile < a.NT;
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
 
-  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks};
-  cs.issue(0);
+  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks, nullptr, nullptr, 0};
+  cs.start();
 
   const auto rb = af_rsrc(a.bias, NS::NL * AF_HID * 4);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
@@ -144,10 +184,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   }
 
   const int a_off8 = (h * 256 + j) * 16;     // lane offset inside a Mpad=256 image chunk
+  const int voff_t = (4 * h * 32 + j) * 4;
   f32x16 acc[8];
   float in[128];
+  TileStore ts{af_rsrc(a.acts, 0), voff_t};
 
-  auto epilogue = [&](int l) {               // relu -> in[], optional stores of X_{l+1} and its sign bits
+  auto relu_out = [&](int l) {               // acc -> in[] = relu(Z_l) = X_{l+1}; its stores are deferred
     uint32_t mk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int T = 0; T < 8; ++T)
@@ -159,32 +201,37 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
       }
     if constexpr (TRAIN) {
       if (live) {
-        store_tile(in, a.acts + ((size_t)l * a.NT + tile) * AF_TILE_F, j, h);
         u32x4 m4 = {mk[0], mk[1], mk[2], mk[3]};
         *(u32x4*)(a.masks + (((size_t)l * a.NT + tile) * 64 + lane) * 4) = m4;
       }
+      ts.r = af_rsrc(a.acts + ((size_t)l * a.NT + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
+  };
+  auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
+  auto hook_dma_store = [&](auto gi) {
+    if constexpr (decltype(gi)::value < 8) cs.issue2();
+    if constexpr (TRAIN) ts.template part<decltype(gi)::value>(in);
   };
 
   // ---- layer 0
   init_bias(acc, rb, 0, h);
   {
     const char* buf = cs.next();
-    mm_block<8, NS::K0G, 0, 4>(acc, pe, buf + a_off8);
+    mm_block<8, NS::K0G, 0, 4>(acc, pe, buf + a_off8, hook_dma);
   }
-  epilogue(0);
+  relu_out(0);
 
   // ---- hidden layers 1 .. NL-2
   for (int l = 1; l <= NS::NL - 2; ++l) {
     init_bias(acc, rb, l, h);
-    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8); }
+    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
+    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
     if constexpr (NS::SKIP != 0) {
-      if ((NS::SKIP >> l) & 1) { const char* buf = cs.next(); mm_block<8, NS::PEG, 0, 4>(acc, pe, buf + a_off8); }
+      if ((NS::SKIP >> l) & 1) { const char* buf = cs.next(); mm_block<8, NS::PEG, 0, 4>(acc, pe, buf + a_off8, hook_dma); }
     }
-    epilogue(l);
+    relu_out(l);
   }
 
   // ---- output layer (one 32-wide tile, OUT real rows), tanh
@@ -197,8 +244,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     }
     const char* buf = cs.next();
     const char* al = buf + (h * 32 + j) * 16;
-    mm_block<1, 32, 0, 4>(acc1, in, al);
-    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) mm_block<1, NS::PEG, 0, 4>(acc1, pe, al + 32 * 2 * 32 * 16);
+    mm_block<1, 32, 0, 4>(acc1, in, al, hook_dma_store);
+    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) mm_block<1, NS::PEG, 0, 4>(acc1, pe, al + 32 * 2 * 32 * 16, hook_dma);
     if (live && h == 0) {
       f32x4 o;
       o[0] = tanhf(acc1[0][0]);
@@ -221,13 +268,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-  int tile = blockIdx.x * 4 + wave;
+  int tile = a.tile0 + blockIdx.x * 4 + wave;
   const bool live = tile < a.NT;
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
 
-  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks};
-  cs.issue(0);
+  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks, nullptr, nullptr, 0};
+  cs.start();
 
   float dzl[4];
   {
@@ -242,8 +289,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   }
 
   const int a_off8 = (h * 256 + j) * 16;
+  const int voff_t = (4 * h * 32 + j) * 4;
   f32x16 acc[8];
   float in[128];
+  TileStore ts{af_rsrc(a.dz, 0), voff_t};
 
   auto zero_acc = [&]() {
 #pragma unroll
@@ -251,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
   };
-  auto epilogue = [&](int l) {      // acc = dX_l; mask with sign bits of X_l (masks[l-1]) -> dZ_{l-1}
+  auto mask_out = [&](int l) {      // acc = dX_l; mask with sign bits of X_l (masks[l-1]) -> in[] = dZ_{l-1}
     const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.NT + tile) * 64 + lane) * 4);
     const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
 #pragma unroll
@@ -260,21 +309,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       for (int r = 0; r < 16; ++r)
         in[T * 16 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
                                                    (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 1], (T & 1) * 16 + r, 1));
-    if (live) store_tile(in, a.dz + ((size_t)(l - 1) * a.NT + tile) * AF_TILE_F, j, h);
+    ts.r = af_rsrc(a.dz + ((size_t)(l - 1) * a.NT + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
   };
+  auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
+  auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); ts.template part<decltype(gi)::value>(in); };
 
   // ---- output layer: K = 8 (one group), only p < OUT non-zero
   zero_acc();
-  { const char* buf = cs.next(); mm_block<8, 1, 0, NS::OUT>(acc, dzl, buf + a_off8); }
-  epilogue(NS::NL - 1);
+  { const char* buf = cs.next(); mm_block<8, 1, 0, NS::OUT>(acc, dzl, buf + a_off8, hook_dma); }
+  mask_out(NS::NL - 1);
 
   for (int l = NS::NL - 2; l >= 1; --l) {
     zero_acc();
-    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8); }
-    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8); }
-    epilogue(l);
+    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
+    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
+    mask_out(l);
   }
 
   if constexpr (NS::DX0) {
@@ -285,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
     for (int T = 0; T < 2; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[T][r] = 0.f;
-    { const char* buf = cs.next(); mm_block<2, 32, 0, 4>(acc2, in, buf + (h * 64 + j) * 16); }
+    { const char* buf = cs.next(); mm_block<2, 32, 0, 4>(acc2, in, buf + (h * 64 + j) * 16, hook_dma_store); }
     const auto r = af_rsrc(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
     float dx0 = 0.f, dx1 = 0.f;
 #pragma unroll
@@ -307,12 +358,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       dst[0] += a.din_scale * dx0;
       dst[1] += a.din_scale * dx1;
     }
+  } else {
+    // dZ_0 of a net whose input needs no gradient: nothing left to hide the stores behind
+    ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
+    ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s) {
-  const dim3 grid((a->NT + 3) / 4), block(256);
+  const dim3 grid((a->NT - a->tile0 + 3) / 4), block(256);
   const size_t lds = 2 * AF_CHUNK_MAX;
 #define AF_FWD(NS)                                                                 \
   do {                                                                             \
@@ -331,7 +386,7 @@ extern "C" int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s
 }
 
 extern "C" int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s) {
-  const dim3 grid((a->NT + 3) / 4), block(256);
+  const dim3 grid((a->NT - a->tile0 + 3) / 4), block(256);
   const size_t lds = 2 * AF_CHUNK_MAX;
   switch (net) {
     case AF_NET_MAP1:  hipLaunchKernelGGL((k_mlp_bwd<NsMap1>),  grid, block, lds, s, *a); break;
