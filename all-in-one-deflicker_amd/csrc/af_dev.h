@@ -52,7 +52,8 @@ struct FwdArgs {
   float in_scale, in_shift0, in_shift1;   // PE nets: x = v*scale + (row < split_row ? shift0 : shift1)
   int split_row;
   int tile0;                  // first row tile of this launch
-  int NT;                     // one past the last row tile (also the tile stride of acts/masks)
+  int NT;                     // one past the last row tile of this launch
+  int nt_stride;              // row tiles per layer plane of acts / masks (the whole batch)
   int nchunks;
 };
 
@@ -71,6 +72,7 @@ struct BwdArgs {
   int nrows;                  // rows that own an input gradient (pad rows are skipped)
   int tile0;
   int NT;
+  int nt_stride;
   int nchunks;
 };
 

@@ -64,7 +64,8 @@ struct TimedEv { int cls; hipEvent_t a, b; };
 
 struct af_handle {
   af_config cfg;
-  int device = 0; hipStream_t stream = nullptr; int ncu = 256;
+  int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; int ncu = 256;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = false;
   std::string err;
   NetDesc nets[AF_MAX_NETS];
   size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0;
@@ -292,7 +293,7 @@ FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, 
   a.wimg = h->img_f + n.f_base; a.chunks = n.d_fchunks; a.bias = h->bias_img + n.bias_base;
   a.in = in; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
-  a.NT = NT; a.nchunks = (int)n.fchunks.size();
+  a.NT = NT; a.nt_stride = NT; a.nchunks = (int)n.fchunks.size();
   return a;
 }
 
@@ -300,7 +301,7 @@ BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
   BwdArgs a{};
   a.wimg = h->img_b + n.b_base; a.chunks = n.d_bchunks; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
   a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
-  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nchunks = (int)n.bchunks.size();
+  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT; a.nchunks = (int)n.bchunks.size();
   return a;
 }
 
@@ -378,7 +379,14 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
 #define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->fail(AF_EHIP, #x, e_); return die(e_ == hipErrorOutOfMemory ? AF_ENOMEM : AF_EHIP); } } while (0)
   hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
   h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  CCHK(hipStreamCreate(&h->stream));
+  {   // main stream = critical path (high priority); stream2 = filler work (low priority)
+    int lo = 0, hi = 0; CCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi)); CCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo));
+  }
+  CCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); CCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  // Two-stream overlap of the atlas-independent mapping rows: measured SLOWER on MI355X (2.01 vs 1.97 ms/step,
+  // profiles/r1_overlap_timeline.txt: the hardware packs the co-running kernels poorly), so it is opt-in.
+  if (const char* e = getenv("AF_OVERLAP")) h->overlap = (e[0] == '1');
   CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_dw_init());
 
   describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
@@ -439,7 +447,10 @@ void af_destroy(af_handle* h) {
   (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table);
   (void)hipFree(h->coords); (void)hipFree(h->x0_tile); (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
   (void)hipFree(h->partial); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -561,15 +572,36 @@ static int ensure_loss_log(af_handle* h, size_t steps) {
 }
 
 // One backward + update tail shared by the main loop and the pre-train: chains, dW, Adam.
+// The mapping rows that do not feed the atlas (row tiles >= tiles_of(3N): rigidity and flow rows) are
+// independent of the atlas kernels, so their forward / backward launches go to a second stream and fill the
+// CUs the atlas kernels and the kernel tails leave idle.  fork(): stream2 waits for everything enqueued on
+// the main stream so far; join(): the main stream waits for stream2.
+static int fork_streams(af_handle* h) {
+  HCHK(hipEventRecord(h->ev_fork, h->stream)); HCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  return 0;
+}
+static int join_streams(af_handle* h) {
+  HCHK(hipEventRecord(h->ev_join, h->stream2)); HCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  return 0;
+}
+
+// One backward + update tail shared by the main loop and the pre-train: chains, dW, Adam.
 static int step_tail(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, bool with_atlas, int NT_map, int NT_atlas, int rows_atlas) {
   NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
+  const bool split = with_atlas && h->overlap && NT_atlas < NT_map;
+  if (split) { int rc = fork_streams(h); if (rc) return rc; }
   if (with_atlas) {
     Timer t(h, 4);
     BwdArgs b = bwd_args(h, A, NT_atlas);
     b.din0 = M.dout; b.nrows = rows_atlas;
     LCHK(af_launch_bwd(AF_NET_ATLAS, &b, h->stream));
   }
-  { Timer t(h, 5); BwdArgs b = bwd_args(h, M, NT_map); LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream)); }
+  if (split) {
+    BwdArgs b = bwd_args(h, M, NT_map); b.tile0 = NT_atlas;
+    LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream2));
+  }
+  { Timer t(h, 5); BwdArgs b = bwd_args(h, M, NT_map); if (split) b.NT = NT_atlas; LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream)); }
+  if (split) { int rc = join_streams(h); if (rc) return rc; }
   { Timer t(h, 6); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
   {
     Timer t(h, 7);
@@ -676,10 +708,18 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
       p.coords = h->coords; p.x0_tile = h->x0_tile; p.samples = h->samples; p.counts = h->counts;
       if (af_launch_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "prep"); break; }
     }
+    const bool split = h->overlap && NT_atlas < NT_map;
+    if (split && (rc = fork_streams(h)) != 0) break;
     { Timer t(h, 1); FwdArgs fa = fwd_args(h, M, h->coords, M.out_buf, NT_map, true);
+      if (split) fa.NT = NT_atlas;
       if (af_launch_fwd(AF_NET_MAP1, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd map"); break; } }
+    if (split) {
+      FwdArgs fb = fwd_args(h, M, h->coords, M.out_buf, NT_map, true); fb.tile0 = NT_atlas;
+      if (af_launch_fwd(AF_NET_MAP1, 1, &fb, h->stream2)) { rc = h->fail(AF_EHIP, "fwd map (stream 2)"); break; }
+    }
     { Timer t(h, 2); FwdArgs fa = fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true);
       if (af_launch_fwd(AF_NET_ATLAS, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd atlas"); break; } }
+    if (split && (rc = join_streams(h)) != 0) break;
     {
       Timer t(h, 3);
       LossArgs l{};

@@ -202,9 +202,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     if constexpr (TRAIN) {
       if (live) {
         u32x4 m4 = {mk[0], mk[1], mk[2], mk[3]};
-        *(u32x4*)(a.masks + (((size_t)l * a.NT + tile) * 64 + lane) * 4) = m4;
+        *(u32x4*)(a.masks + (((size_t)l * a.nt_stride + tile) * 64 + lane) * 4) = m4;
       }
-      ts.r = af_rsrc(a.acts + ((size_t)l * a.NT + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+      ts.r = af_rsrc(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
   };
   auto mask_out = [&](int l) {      // acc = dX_l; mask with sign bits of X_l (masks[l-1]) -> in[] = dZ_{l-1}
-    const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.NT + tile) * 64 + lane) * 4);
+    const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.nt_stride + tile) * 64 + lane) * 4);
     const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
 #pragma unroll
     for (int T = 0; T < 8; ++T)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       for (int r = 0; r < 16; ++r)
         in[T * 16 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
                                                    (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 1], (T & 1) * 16 + r, 1));
-    ts.r = af_rsrc(a.dz + ((size_t)(l - 1) * a.NT + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    ts.r = af_rsrc(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); ts.template part<decltype(gi)::value>(in); };

@@ -28,13 +28,13 @@ int main(int argc, char** argv) {
   std::vector<float> w(off / 4); for (auto& x : w) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
   CK(hipMemcpy(img, w.data(), off, hipMemcpyHostToDevice));
   FwdArgs fa{}; fa.wimg = img; fa.chunks = dch; fa.bias = bias; fa.in = in; fa.out = out; fa.acts = acts; fa.masks = masks;
-  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nchunks = (int)ch.size();
+  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.nchunks = (int)ch.size();
   // backward chunk order: [8K, 16 x 64K]
   std::vector<AfChunk> bch; off = 0; bch.push_back({off, 8192}); off += 8192;
   for (int i = 0; i < 16; ++i) { bch.push_back({off, 65536}); off += 65536; }
   AfChunk* dbch; CK(hipMalloc(&dbch, bch.size() * sizeof(AfChunk))); CK(hipMemcpy(dbch, bch.data(), bch.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
   BwdArgs ba{}; ba.wimg = img; ba.chunks = dbch; ba.out = out; ba.dout = in; ba.masks = masks; ba.dz = dz; ba.dz_last = dzl;
-  ba.split_row = 1 << 30; ba.NT = NT; ba.nchunks = (int)bch.size();
+  ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT; ba.nchunks = (int)bch.size();
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int which = 0; which < 2; ++which) {
     for (int r = 0; r < 3; ++r) { if (which == 0) af_launch_fwd(AF_NET_MAP1, 1, &fa, 0); else af_launch_bwd(AF_NET_MAP1, &ba, 0); }
