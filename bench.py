@@ -114,6 +114,34 @@ def cpu_baseline(resx, resy, nframes, seed, sds, video_dev, budget_s):
             "sample": "%d loop iterations (N=10000, alternating with/without the global-rigidity term) of the oracle restatement, %.1f s" % (n, dt)}
 
 
+def timed_region(run, sync, dist=None, device=None):
+    """Barrier + sync, run(), sync + barrier; returns the MAX over ranks of the elapsed seconds
+    (the contract's timing rule).  `dist` is torch.distributed when world_size > 1."""
+    import torch
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def shard_for_rank(rank, world, n_videos=None):
+    """Independent videos shard one per GPU: rank r owns videos r, r+world, ... (seeds double as video ids)."""
+    n_videos = world if n_videos is None else n_videos
+    return list(range(rank, n_videos, world))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +162,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -143,7 +172,7 @@ def main():
     cfg = aiod_amd.default_config(args.resx, args.resy, args.frames)
     N = cfg.samples_batch
     af = aiod_amd.AtlasFit(cfg, device=local)
-    video = synth_video_device(args.resx, args.resy, args.frames, seed=rank, device=dev)
+    video = synth_video_device(args.resx, args.resy, args.frames, seed=shard_for_rank(rank, world)[0], device=dev)
     af.upload_video(*video)
     sds = init_state_dicts(1234 + rank)
     af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1])
@@ -156,11 +185,6 @@ def main():
     first = max(0, switch - K // 2)
     classes = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam")
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # ---- warm-up (W untimed steps, all kernel classes timed to find the dominant one)
     af.set_timing(0xFF)
@@ -172,16 +196,9 @@ def main():
     af.set_timing(1 << classes.index(dom))                         # events only around the dominant kernel
 
     # ---- timed region: EXACTLY K steps
-    barrier()
-    t0 = time.perf_counter()
-    af.train_steps(first, K, None, seed=rank, return_losses=False)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_region(lambda: af.train_steps(first, K, None, seed=rank, return_losses=False),
+                      torch.cuda.synchronize, dist if world > 1 else None, dev)
     tk = af.timing(reset=True)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     # ---- roofline of the dominant kernel: algorithmic FLOPs per launch / mean HIP-event duration
     flops_launch = 0.0
