@@ -5,16 +5,17 @@
 #include <stdlib.h>
 #include <vector>
 #include "../all-in-one-deflicker_amd/csrc/mlp.hip"
+#include "experiments/mlp16.hip"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
   const int NT = argc > 1 ? atoi(argv[1]) : 2813;
   const int reps = 20;
-  af_mlp_init();
+  af_mlp_init(); af_mlp16_init();
   // mapping net: chunks [8K, 16 x 64K, 32K]
   std::vector<AfChunk> ch; uint32_t off = 0;
-  ch.push_back({off, 8192}); off += 8192;
+  ch.push_back({off, 16384}); off += 16384;
   for (int i = 0; i < 16; ++i) { ch.push_back({off, 65536}); off += 65536; }
   ch.push_back({off, 32768}); off += 32768;
   float *img, *bias, *in, *out, *acts, *dz, *dzl; uint32_t* masks; AfChunk* dch;
@@ -30,21 +31,25 @@ int main(int argc, char** argv) {
   FwdArgs fa{}; fa.wimg = img; fa.chunks = dch; fa.bias = bias; fa.in = in; fa.out = out; fa.acts = acts; fa.masks = masks;
   fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.nchunks = (int)ch.size();
   // backward chunk order: [8K, 16 x 64K]
-  std::vector<AfChunk> bch; off = 0; bch.push_back({off, 8192}); off += 8192;
+  std::vector<AfChunk> bch; off = 0; bch.push_back({off, 16384}); off += 16384;
   for (int i = 0; i < 16; ++i) { bch.push_back({off, 65536}); off += 65536; }
   AfChunk* dbch; CK(hipMalloc(&dbch, bch.size() * sizeof(AfChunk))); CK(hipMemcpy(dbch, bch.data(), bch.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
   BwdArgs ba{}; ba.wimg = img; ba.chunks = dbch; ba.out = out; ba.dout = in; ba.masks = masks; ba.dz = dz; ba.dz_last = dzl;
   ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT; ba.nchunks = (int)bch.size();
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int which = 0; which < 2; ++which) {
-    for (int r = 0; r < 3; ++r) { if (which == 0) af_launch_fwd(AF_NET_MAP1, 1, &fa, 0); else af_launch_bwd(AF_NET_MAP1, &ba, 0); }
+  for (int which = 0; which < 4; ++which) {
+    auto go = [&]() {
+      if (which == 0) af_launch_fwd(AF_NET_MAP1, 1, &fa, 0); else if (which == 1) af_launch_bwd(AF_NET_MAP1, &ba, 0);
+      else if (which == 2) af_launch_fwd16(AF_NET_MAP1, 1, &fa, 0); else af_launch_bwd16(AF_NET_MAP1, &ba, 0);
+    };
+    for (int r = 0; r < 3; ++r) go();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) { if (which == 0) af_launch_fwd(AF_NET_MAP1, 1, &fa, 0); else af_launch_bwd(AF_NET_MAP1, &ba, 0); }
+    for (int r = 0; r < reps; ++r) go();
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-    const double fl = (double)NT * 32 * (which == 0 ? 526848.0 : 525312.0);
-    printf("ABL=%d %s NT=%d: %.4f ms  %.1f TF (%.1f%% of 157.3)\n", AF_ABL, which == 0 ? "fwd_map" : "bwd_map", NT, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+    const double fl = (double)NT * 32 * ((which & 1) == 0 ? 526848.0 : 525312.0);
+    printf("ABL=%d %s NT=%d: %.4f ms  %.1f TF (%.1f%% of 157.3)\n", AF_ABL, which == 0 ? "fwd_map32" : which == 1 ? "bwd_map32" : which == 2 ? "fwd_map16" : "bwd_map16", NT, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
   }
   return 0;
 }
