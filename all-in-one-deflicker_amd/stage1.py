@@ -1,0 +1,284 @@
+"""Drop-in stage-1 entry point: same flags, config keys, on-disk inputs and results tree as the reference's
+`src/stage1_neural_atlas.py` (CLI :257-281, main :27-255), with the optimisation loop running in
+libatlasfit.so.  Host-side pieces restated here (numpy / PIL only — cv2, imageio, skimage, tensorboard are not
+required): the input builder `load_input_data_single` (src/models/stage_1/unwrap_utils.py:105-163 incl.
+`resize_flow` :33-38 and `compute_consistency` :10-23), and the parts of `evaluate_model_single`
+(src/models/stage_1/evaluate.py:605-793) that stage 2 and the metric consume: the checkpoint (:616-622), the
+reconstructed frames `output/%05d.png` with the reference's truncating uint8 cast (:732-733) and the
+`PSNR_<mean>` marker file (:740-743,781-783).  The debug mp4 / matplotlib panels / tensorboard images are not
+produced (out of scope).
+
+    python all-in-one-deflicker_amd/stage1.py --vid_name <name> [--config config_flow_100.json] [--root data/test/] [--down 4] [--gpu 0]
+"""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------------------------
+# input builder (unwrap_utils.py)
+def resize_bilinear(img, new_w, new_h):
+    """cv2.resize(img, (new_w, new_h)) with the default INTER_LINEAR: half-pixel centres, edge clamping,
+    no anti-aliasing.  img: (H, W[, C]) float array."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    if (h, w) == (new_h, new_w):
+        return img.copy()
+    sx, sy = w / new_w, h / new_h
+    fx = (np.arange(new_w, dtype=np.float64) + 0.5) * sx - 0.5
+    fy = (np.arange(new_h, dtype=np.float64) + 0.5) * sy - 0.5
+    x0 = np.floor(fx).astype(np.int64); y0 = np.floor(fy).astype(np.int64)
+    ax = (fx - x0); ay = (fy - y0)
+    x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
+    y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
+    if img.ndim == 3:
+        ax_, ay_ = ax[None, :, None], ay[:, None, None]
+    else:
+        ax_, ay_ = ax[None, :], ay[:, None]
+    top = img[y0c][:, x0c] * (1 - ax_) + img[y0c][:, x1c] * ax_
+    bot = img[y1c][:, x0c] * (1 - ax_) + img[y1c][:, x1c] * ax_
+    return (top * (1 - ay_) + bot * ay_).astype(img.dtype)
+
+
+def resize_flow(flow, newh, neww):
+    """unwrap_utils.py:33-38 (u is scaled by newh/oldh and v by neww/oldw, as the reference does)."""
+    oldh, oldw = flow.shape[0:2]
+    flow = resize_bilinear(flow.astype(np.float32), neww, newh)
+    flow[:, :, 0] *= newh / oldh
+    flow[:, :, 1] *= neww / oldw
+    return flow
+
+
+def _remap_bilinear_zero(img, mapx, mapy):
+    """cv2.remap(img, map, None, INTER_LINEAR), constant-0 border (unwrap_utils.py:22)."""
+    h, w = img.shape[:2]
+    x0 = np.floor(mapx).astype(np.int64); y0 = np.floor(mapy).astype(np.int64)
+    fx = (mapx - x0).astype(np.float32)[..., None]; fy = (mapy - y0).astype(np.float32)[..., None]
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+        return np.where(ok[..., None], v, 0.0).astype(np.float32)
+
+    return (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy)
+            + tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
+
+
+def compute_consistency(flow12, flow21):
+    """unwrap_utils.py:10-23."""
+    h, w = flow12.shape[:2]
+    mapx = flow12[:, :, 0] + np.arange(w, dtype=np.float32)
+    mapy = flow12[:, :, 1] + np.arange(h, dtype=np.float32)[:, None]
+    diff = flow12 + _remap_bilinear_zero(flow21, mapx, mapy)
+    return (diff[:, :, 0] ** 2 + diff[:, :, 1] ** 2) ** 0.5
+
+
+def load_input_data_single(resy, resx, maximum_number_of_frames, data_folder, filter_optical_flow, vid_root, vid_name):
+    """unwrap_utils.py:105-163.  Returns numpy fp32 arrays in the reference's layouts:
+    video_frames (resy,resx,3,F), optical_flows / _reverse (resy,resx,2,F,1), masks (resy,resx,F,1)."""
+    from PIL import Image
+    data_folder, vid_root = Path(data_folder), Path(vid_root)
+    out_flow_dir = vid_root / f"{vid_name}_flow"
+    input_files = sorted(list(data_folder.glob("*.jpg")) + list(data_folder.glob("*.png")))
+    if not input_files:
+        raise FileNotFoundError("no *.jpg / *.png frames under %s" % data_folder)
+    F = int(np.minimum(maximum_number_of_frames, len(input_files)))
+    video_frames = np.zeros((resy, resx, 3, F), np.float32)
+    optical_flows = np.zeros((resy, resx, 2, F, 1), np.float32)
+    optical_flows_mask = np.zeros((resy, resx, F, 1), np.float32)
+    optical_flows_reverse = np.zeros((resy, resx, 2, F, 1), np.float32)
+    optical_flows_reverse_mask = np.zeros((resy, resx, F, 1), np.float32)
+    for i in range(F):
+        im = np.array(Image.open(str(input_files[i]))).astype(np.float64) / 255.0
+        if im.ndim == 2:
+            im = np.tile(im[:, :, None], [1, 1, 3])
+        video_frames[:, :, :, i] = resize_bilinear(im[:, :, :3], resx, resy).astype(np.float32)
+    for i in range(F - 1):
+        fn1, fn2 = input_files[i].name, input_files[i + 1].name
+        f12p, f21p = out_flow_dir / f"{fn1}_{fn2}.npy", out_flow_dir / f"{fn2}_{fn1}.npy"
+        if not f12p.exists() or not f21p.exists():
+            raise FileNotFoundError("optical flow %s missing: run the reference's src/preprocess_optical_flow.py (RAFT on "
+                                    "PyTorch-ROCm, out of scope of this library) first" % f12p)
+        flow12, flow21 = np.load(f12p).astype(np.float32), np.load(f21p).astype(np.float32)
+        if flow12.shape[0] != resy or flow12.shape[1] != resx:
+            flow12 = resize_flow(flow12, newh=resy, neww=resx)
+            flow21 = resize_flow(flow21, newh=resy, neww=resx)
+        optical_flows[:, :, :, i, 0] = flow12
+        optical_flows_reverse[:, :, :, i + 1, 0] = flow21
+        if filter_optical_flow:
+            optical_flows_mask[:, :, i, 0] = compute_consistency(flow12, flow21) < 1.0
+            optical_flows_reverse_mask[:, :, i + 1, 0] = compute_consistency(flow21, flow12) < 1.0
+        else:
+            optical_flows_mask[:, :, i, 0] = 1.0
+            optical_flows_reverse_mask[:, :, i + 1, 0] = 1.0
+    return optical_flows_mask, video_frames, optical_flows_reverse_mask, optical_flows_reverse, optical_flows
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint format (evaluate.py:616-622; resume stage1_neural_atlas.py:141-146)
+def _torch_modules(sd_map, sd_atlas):
+    import torch
+    from .atlasfit import NET_ATLAS, NET_MAPPING1, imlp_shapes
+
+    def build(net, sd):
+        m = torch.nn.Module()
+        m.hidden = torch.nn.ModuleList([torch.nn.Linear(k, o) for (o, k) in imlp_shapes(net)])
+        m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+        return m
+    return build(NET_MAPPING1, sd_map), build(NET_ATLAS, sd_atlas)
+
+
+def save_checkpoint(af, path, iteration):
+    """torch.save of the reference's dict: F_atlas_state_dict, iteration, model_F_mapping1_state_dict,
+    optimizer_all_state_dict (a genuine torch.optim.Adam state dict, param order mapping then atlas)."""
+    import torch
+    from .atlasfit import NET_ATLAS, NET_MAPPING1
+    mm, ma = _torch_modules(af.state_dict(NET_MAPPING1), af.state_dict(NET_ATLAS))
+    opt = torch.optim.Adam([{"params": list(mm.parameters())}, {"params": list(ma.parameters())}], lr=float(af.cfg.lr))
+    for net, mod in ((NET_MAPPING1, mm), (NET_ATLAS, ma)):
+        m, v, step = af.adam_state(net)
+        off = 0
+        for p in mod.parameters():
+            n = p.numel()
+            opt.state[p] = {"step": torch.tensor(float(step)), "exp_avg": torch.from_numpy(m[off:off + n].reshape(p.shape).copy()),
+                            "exp_avg_sq": torch.from_numpy(v[off:off + n].reshape(p.shape).copy())}
+            off += n
+    torch.save({"F_atlas_state_dict": ma.state_dict(), "iteration": iteration,
+                "model_F_mapping1_state_dict": mm.state_dict(), "optimizer_all_state_dict": opt.state_dict()}, str(path))
+
+
+def load_checkpoint(af, path):
+    import torch
+    from .atlasfit import NET_ATLAS, NET_MAPPING1, imlp_shapes
+    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    af.load_state_dict(NET_MAPPING1, ck["model_F_mapping1_state_dict"])
+    af.load_state_dict(NET_ATLAS, ck["F_atlas_state_dict"])
+    st = ck["optimizer_all_state_dict"]["state"]
+    idx, step = 0, 0
+    for net in (NET_MAPPING1, NET_ATLAS):
+        ms, vs = [], []
+        for (o, k) in imlp_shapes(net):
+            for _ in range(2):               # weight, bias
+                s = st[idx]; idx += 1
+                ms.append(s["exp_avg"].reshape(-1).numpy()); vs.append(s["exp_avg_sq"].reshape(-1).numpy()); step = int(s["step"])
+        af.set_adam_state(net, np.concatenate(ms), np.concatenate(vs), step)
+    return int(ck["iteration"])
+
+
+# ---------------------------------------------------------------------------------------------
+def evaluate_model_single(af, video_frames, results_folder, iteration, save_checkpoint_file=True):
+    """The stage-2 hand-off + metric of evaluate.py:605-793: checkpoint, output/%05d.png, <iter>/PSNR_<mean>."""
+    from PIL import Image
+    results_folder = Path(results_folder)
+    eval_dir = results_folder / ("%06d" % iteration)
+    (results_folder / "output").mkdir(parents=True, exist_ok=True)
+    eval_dir.mkdir(parents=True, exist_ok=True)
+    if save_checkpoint_file:
+        save_checkpoint(af, results_folder / "checkpoint", iteration)
+    F = video_frames.shape[3]
+    psnrs = np.zeros(F)
+    for f in range(F):
+        rec, sse = af.render_frame(f)
+        Image.fromarray((rec.astype(np.float64) * 255).astype(np.uint8)).save(str(results_folder / "output" / ("%05d.png" % f)))
+        psnrs[f] = 10.0 * np.log10(1.0 / (sse / rec.size))
+    print(psnrs.mean())
+    open(eval_dir / ("PSNR_%f" % psnrs.mean()), "a").close()
+    return float(psnrs.mean())
+
+
+def main(config, args):
+    """stage1_neural_atlas.py:27-255 with the loop in libatlasfit.so."""
+    from PIL import Image
+    from . import atlasfit as A
+    import glob
+    frames_list = sorted(glob.glob(os.path.join(args.vid_path, "*g")))
+    if not frames_list:
+        raise FileNotFoundError("no frames under %s" % args.vid_path)
+    w, h = Image.open(frames_list[0]).size
+    resx, resy = w, h
+    if args.down is not None:
+        resx, resy = int(resx / args.down), int(resy / args.down)
+    iters_num = config["iters_num"]
+    evaluate_every = int(config["evaluate_every"])
+    data_folder = Path(args.vid_path)
+    vid_name, vid_root = data_folder.name, data_folder.parent
+    results_folder = Path("./results/%s/stage_1" % vid_name)
+    results_folder.mkdir(parents=True, exist_ok=True)
+    with open(results_folder / "config.json", "w") as f:
+        json.dump(config, f, indent=4)
+    flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
+        resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
+    F = video_frames.shape[3]
+    af = A.AtlasFit(A.default_config(resx, resy, F, config), device=getattr(args, "device_ordinal", 0))
+    af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask)
+    import torch
+    seed = getattr(args, "seed", None)
+    if seed is not None:
+        torch.manual_seed(seed)
+    start_iteration = 0
+    if not config["load_checkpoint"]:
+        sds = {}
+        for net in (A.NET_MAPPING1, A.NET_ATLAS):          # nn.Linear default init, reference construction order (:112-128)
+            sd = {}
+            for i, (o, k) in enumerate(A.imlp_shapes(net)):
+                lin = torch.nn.Linear(k, o)
+                sd["hidden.%d.weight" % i] = lin.weight.detach(); sd["hidden.%d.bias" % i] = lin.bias.detach()
+            sds[net] = sd
+        af.load_state_dict(A.NET_MAPPING1, sds[A.NET_MAPPING1]); af.load_state_dict(A.NET_ATLAS, sds[A.NET_ATLAS])
+        if config["pretrain_mapping1"]:
+            print("pre-training")
+            af.pre_train_mapping(config["pretrain_iter_number"], seed=int(torch.randint(2 ** 31, (1,))))
+    else:
+        start_iteration = load_checkpoint(af, config["checkpoint_path"])
+    sampler_seed = int(torch.randint(2 ** 31, (1,)))
+    i = start_iteration
+    last_psnr = None
+    while i < iters_num:
+        # run up to (and including) the next evaluation iteration in one call; evaluate when i % evaluate_every == 0 and i > start
+        nxt = ((i // evaluate_every) + 1) * evaluate_every
+        stop = min(iters_num - 1, nxt)
+        af.train_steps(i, stop - i + 1, None, seed=sampler_seed, return_losses=False)
+        i = stop + 1
+        if stop % evaluate_every == 0 and stop > start_iteration:
+            last_psnr = evaluate_model_single(af, video_frames, results_folder, stop)
+    af.close()
+    return last_psnr
+
+
+def _cli(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", type=str, default="config_flow_100.json")
+    parser.add_argument("--vid_name", type=str, default="Around_the_world_in_1896_001")
+    parser.add_argument("--root", type=str, default="data/test/")
+    parser.add_argument("--down", type=int, default=4)
+    parser.add_argument("--gpu", type=int, default=0)
+    parser.add_argument("--seed", type=int, default=None, help="(extension) seed torch's RNG for reproducible runs")
+    args = parser.parse_args(argv)
+    os.environ["CUDA_VISIBLE_DEVICES"] = "%d" % args.gpu        # reference :267-268 (HIP honours it on ROCm)
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", "%d" % args.gpu)
+    args.device_ordinal = 0
+    args.vid_path = os.path.join(args.root, args.vid_name)
+    cfg_path = args.config if os.path.exists(args.config) else os.path.join("src/config", args.config)
+    if os.path.exists(cfg_path):
+        with open(cfg_path) as f:
+            config = json.load(f)
+    else:
+        from .atlasfit import REFERENCE_CONFIG
+        print("config %s not found: using the shipped hyper-parameters" % cfg_path)
+        config = dict(REFERENCE_CONFIG)
+    return main(config, args)
+
+
+if __name__ == "__main__":
+    if __package__ in (None, ""):
+        sys.path.insert(0, os.path.dirname(_HERE))
+        import aiod_amd  # noqa: F401
+        from aiod_amd import stage1 as _s
+        sys.exit(0 if _s._cli() is not None or True else 1)
+    _cli()
