@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "af_create", "af_destroy", "af_last_error", "af_upload_video", "af_param_count", "af_set_params",
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
-    "af_set_timing", "af_get_timing", "af_step_work",
+    "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size",
 ]
 
 
@@ -49,7 +49,17 @@ class AfConfig(C.Structure):
         ("uv_mapping_scale", C.c_float),
         ("lr", C.c_float),
         ("pretrain_batch", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        # fg/bg dual-atlas path (src/stage1_neural_atlas_seg.py); read only when two_layer != 0
+        ("two_layer", C.c_int32),
+        ("number_of_channels_mapping2", C.c_int32), ("number_of_layers_mapping2", C.c_int32),
+        ("number_of_channels_alpha", C.c_int32), ("number_of_layers_alpha", C.c_int32),
+        ("positional_encoding_num_alpha", C.c_int32),
+        ("use_positional_encoding_mapping2", C.c_int32),
+        ("global_rigidity_derivative_amount_bg", C.c_int32),
+        ("stop_bootstrapping_iteration", C.c_int32),
+        ("global_rigidity_coeff_bg", C.c_float),
+        ("alpha_bootstrapping_factor", C.c_float), ("alpha_flow_factor", C.c_float), ("sparsity_coeff", C.c_float),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -72,13 +82,27 @@ REFERENCE_CONFIG = {
 }
 
 
-def default_config(resx, resy, number_of_frames, config=None, **over):
-    """af_config from the reference's JSON config dict (keys as read at stage1_neural_atlas.py:28-90)."""
+def default_config(resx, resy, number_of_frames, config=None, two_layer=False, **over):
+    """af_config from the reference's JSON config dict (keys as read at stage1_neural_atlas.py:28-90, or
+    stage1_neural_atlas_seg.py:27-107 when two_layer)."""
     cfg = dict(REFERENCE_CONFIG)
     if config:
         cfg.update(config)
     cfg.update(over)
     c = AfConfig()
+    c.two_layer = int(bool(two_layer))
+    c.number_of_channels_mapping2 = int(cfg["number_of_channels_mapping2"])
+    c.number_of_layers_mapping2 = int(cfg["number_of_layers_mapping2"])
+    c.number_of_channels_alpha = int(cfg["number_of_channels_alpha"])
+    c.number_of_layers_alpha = int(cfg["number_of_layers_alpha"])
+    c.positional_encoding_num_alpha = int(cfg["positional_encoding_num_alpha"])
+    c.use_positional_encoding_mapping2 = int(bool(cfg["use_positional_encoding_mapping2"]))
+    c.global_rigidity_derivative_amount_bg = int(cfg["global_rigidity_derivative_amount_bg"])
+    c.stop_bootstrapping_iteration = int(cfg["stop_bootstrapping_iteration"])
+    c.global_rigidity_coeff_bg = float(cfg["global_rigidity_coeff_bg"])
+    c.alpha_bootstrapping_factor = float(cfg["alpha_bootstrapping_factor"])
+    c.alpha_flow_factor = float(cfg["alpha_flow_factor"])
+    c.sparsity_coeff = float(cfg["sparsity_coeff"])
     c.resx, c.resy, c.number_of_frames = int(resx), int(resy), int(number_of_frames)
     c.samples_batch = int(cfg["samples_batch"])
     c.number_of_channels_mapping1 = int(cfg["number_of_channels_mapping1"])
@@ -135,11 +159,15 @@ def load_library(path=None):
         "af_get_last_grads": (i32, [vp, i32, vp, sz]),
         "af_set_timing": (i32, [vp, i32]),
         "af_get_timing": (i32, [vp, vp, vp, i32]),
-        "af_step_work": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
+        "af_step_work": (i32, [vp, i32, C.POINTER(i64 * 4), C.POINTER(C.c_double)]),
+        "af_loss_width": (i32, [vp]),
+        "af_config_size": (sz, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
+    if lib.af_config_size() != C.sizeof(AfConfig):
+        raise AtlasFitError(-101, "af_config mirror (%d B) does not match libatlasfit.so (%d B): rebuild" % (C.sizeof(AfConfig), lib.af_config_size()))
     _lib = lib
     return lib
 
@@ -152,13 +180,17 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-# layer shapes of the two IMLPs of the single-atlas path (stage1_neural_atlas.py:112-128)
-def imlp_shapes(net, pe_atlas=10):
+# layer shapes of the IMLPs (stage1_neural_atlas.py:112-128; stage1_neural_atlas_seg.py:127-161)
+def imlp_shapes(net, pe_atlas=10, pe_alpha=5):
     if net == NET_MAPPING1:
         dims = [(256, 3)] + [(256, 256)] * 4 + [(2, 256)]
+    elif net == NET_MAPPING2:
+        dims = [(256, 3)] + [(256, 256)] * 2 + [(2, 256)]
     elif net == NET_ATLAS:
         e = 4 * pe_atlas
         dims = [(256, e), (256, 256), (256, 256), (256, 256), (256, 256 + e), (256, 256), (256, 256), (3, 256 + e)]
+    elif net == NET_ALPHA:
+        dims = [(256, 6 * pe_alpha)] + [(256, 256)] * 6 + [(1, 256)]
     else:
         raise ValueError("net")
     return dims
@@ -188,6 +220,10 @@ class AtlasFit:
     """One video on one MI355X.  Mirrors the objects of stage1_neural_atlas.main()."""
 
     LOSS_NAMES = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total", "valid_fwd", "valid_bwd")
+    LOSS_NAMES_TWO_LAYER = ("rgb", "gradient", "rigidity1", "rigidity2", "global_rigidity1", "global_rigidity2", "flow1", "flow2",
+                            "flow_alpha", "alpha_bootstrapping", "sparsity", "total", "valid_fwd", "valid_bwd", "_", "_")
+    TIMING_NAMES = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam",
+                    "fwd_map2", "fwd_alpha", "bwd_map2", "bwd_alpha")
 
     def __init__(self, cfg, device=0):
         self.lib = load_library()
@@ -198,6 +234,9 @@ class AtlasFit:
             raise AtlasFitError(rc, self.lib.af_last_error(None).decode())
         self.h = h
         self.N = cfg.samples_batch
+        self.two_layer = bool(cfg.two_layer)
+        self.nets = (NET_MAPPING1, NET_MAPPING2, NET_ATLAS, NET_ALPHA) if self.two_layer else (NET_MAPPING1, NET_ATLAS)
+        self.loss_width = int(self.lib.af_loss_width(h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -275,7 +314,7 @@ class AtlasFit:
 
     # ---- the loop body (stage1_neural_atlas.py:151-231)
     def train_steps(self, first_iter, n_iters, inds=None, seed=0, return_losses=True):
-        losses = np.zeros((n_iters, 8), np.float32) if return_losses else None
+        losses = np.zeros((n_iters, self.loss_width), np.float32) if return_losses else None
         if inds is not None:
             inds = np.ascontiguousarray(inds, np.int64)
             assert inds.size == n_iters * self.N, (inds.shape, n_iters, self.N)
@@ -311,19 +350,19 @@ class AtlasFit:
         self._chk(self.lib.af_get_last_grads(self.h, net, _ptr(g), g.size))
         return g
 
-    def set_timing(self, mask=0xFF):
-        self._chk(self.lib.af_set_timing(self.h, int(mask) if not isinstance(mask, bool) else (0xFF if mask else 0)))
+    def set_timing(self, mask=0xFFFF):
+        self._chk(self.lib.af_set_timing(self.h, int(mask) if not isinstance(mask, bool) else (0xFFFF if mask else 0)))
 
     def timing(self, reset=True):
-        ms = np.zeros(8, np.float64); cnt = np.zeros(8, np.int64)
+        ms = np.zeros(16, np.float64); cnt = np.zeros(16, np.int64)
         self._chk(self.lib.af_get_timing(self.h, _ptr(ms), _ptr(cnt), int(reset)))
-        names = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam")
-        return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt)}
+        return {n: (float(m), int(c)) for n, m, c in zip(self.TIMING_NAMES, ms, cnt)}
 
     def step_work(self, it):
-        rm, ra, fl = C.c_int64(0), C.c_int64(0), C.c_double(0)
-        self._chk(self.lib.af_step_work(self.h, int(it), C.byref(rm), C.byref(ra), C.byref(fl)))
-        return int(rm.value), int(ra.value), float(fl.value)
+        """(rows per net indexed by NET_*, fwd+bwd FLOPs) of one loop iteration."""
+        rows, fl = (C.c_int64 * 4)(), C.c_double(0)
+        self._chk(self.lib.af_step_work(self.h, int(it), C.byref(rows), C.byref(fl)))
+        return [int(r) for r in rows], float(fl.value)
 
     def sync(self):
         self._chk(self.lib.af_sync(self.h))

@@ -28,6 +28,7 @@
 #define AF_MAX_LAYERS 8
 #define AF_MAX_NETS   4
 #define AF_REC_F      16            // floats per pixel record (64 B)
+#define AF_LOSS_W     16            // floats per loss record: 14 partial sums + #valid fwd + #valid bwd
 
 enum { AF_NET_MAP1 = 0, AF_NET_ATLAS = 1, AF_NET_MAP2 = 2, AF_NET_ALPHA = 3 };
 enum { AF_IN_XYT = 0, AF_IN_PE2 = 1, AF_IN_PE3 = 2 };
@@ -45,6 +46,7 @@ struct FwdArgs {
   const AfChunk* chunks;      // chunk table for this net (forward order)
   const float* bias;          // [NL][256] padded biases
   const float* in;            // [rows_pad][4]  xyt coords, or uv (PE nets use .x,.y[,.z])
+  const float* in1;           // rows >= split_row read in1[row - split_row] (second mapping net of the fg/bg path)
   float* out;                 // [rows_pad][4]  tanh outputs
   float* acts;                // X_1..X_{NL-1}: [NL-1][NT][256][32]      (train only)
   uint32_t* masks;            // relu bits:     [NL-1][NT][64][4]        (train only)

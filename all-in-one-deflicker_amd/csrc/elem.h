@@ -20,20 +20,41 @@ struct PrepArgs {
   int N, resx, resy, F;
   float half_main, half_grad, half_frames;   // larger_dim/2, resx/2, F/2
   int d_local, d_global, nseg;
-  float* coords;          // [rows_pad][4]
+  float* coords;          // [rows_pad][4]   mapping1 rows
   float* x0_tile;         // [NT][32][32]
   float* samples;         // [N][16]
   int* counts;            // [2]
+  // fg/bg path (stage1_neural_atlas_seg.py): mapping2 sees the same rows except the global-rigidity
+  // neighbours (its own finite-difference distance); the alpha net sees segments 0,1,2,5,6.
+  float* coords2;         // null in the single-atlas path
+  float* x0_tile2;
+  float* coordsA;         // [5N pad][4]
+  int d_global2;
 };
 
 struct LossArgs {
   const float* samples; const float* out_map; const float* out_atlas;
   float* dout_map; float* dout_atlas;
   const int* counts;
-  float* loss_part;       // [nblocks][8]: rgb, gradient, rigidity, global rigidity, flow fwd, flow bwd (sums)
+  float* loss_part;       // [nblocks][AF_LOSS_W]: rgb, gradient, rigidity, global rigidity, flow fwd, flow bwd (sums)
   int N, nseg;
   float L, uv_scale; int d_local, d_global;
   float c_rgb, c_grad, c_rig, c_grig, c_flow;
+};
+
+// Loss stack of the fg/bg path (stage1_neural_atlas_seg.py:220-311).  Row layouts: mapping nets as in PrepArgs
+// (segment s, sample n -> row s*N+n); alpha net rows {centre, (x,y+1), (x+1,y), fwd match, bwd match};
+// atlas rows {m1 centre, m1 (x,y+1), m1 (x+1,y), m2 centre, m2 (x,y+1), m2 (x+1,y)}.
+// loss_part sums: 0 rgb, 1 gradient, 2 rigidity1, 3 rigidity2, 4 global rigidity1, 5 global rigidity2,
+// 6 flow1 fwd, 7 flow1 bwd, 8 flow2 fwd, 9 flow2 bwd, 10 alpha-flow fwd, 11 alpha-flow bwd, 12 BCE, 13 sparsity.
+struct LossSegArgs {
+  const float* samples;
+  const float* out_m1; const float* out_m2; const float* out_alpha; const float* out_atlas;
+  float* dout_m1; float* dout_m2; float* dout_alpha; float* dout_atlas;
+  const int* counts; float* loss_part;
+  int N, nseg;
+  float L, uv_scale; int d_local, d_global_fg, d_global_bg;
+  float c_rgb, c_grad, c_rig, c_grig_fg, c_grig_bg, c_flow, c_boot, c_aflow, c_sparse;
 };
 
 struct PrePrepArgs {

@@ -62,12 +62,22 @@ __global__ void k_pack_table(PackArgs a) {
 // Batch preparation (stage1_neural_atlas.py:159-171; loss_utils.py:137-151, 230-233, 326-351).
 // Row segments of the mapping batch: 0 centre, 1 (x,y+1), 2 (x+1,y), 3 (x,y-d), 4 (x-d,y), 5 fwd-flow match,
 // 6 bwd-flow match, 7 (x,y-D), 8 (x-D,y); segments 7,8 exist only while the global rigidity term is on.
-AF_DEV void put_row(const PrepArgs& a, int seg, int n, float x, float y, float t) {
-  const size_t r = (size_t)seg * a.N + n;
+AF_DEV void put_row_to(float* coords, float* x0_tile, size_t r, float x, float y, float t) {
   f32x4 v = {x, y, t, 0.f};
-  *(f32x4*)(a.coords + r * 4) = v;
-  float* tl = a.x0_tile + (r >> 5) * 1024 + (r & 31);
-  tl[0] = x; tl[32] = y; tl[64] = t;
+  *(f32x4*)(coords + r * 4) = v;
+  if (x0_tile) {
+    float* tl = x0_tile + (r >> 5) * 1024 + (r & 31);
+    tl[0] = x; tl[32] = y; tl[64] = t;
+  }
+}
+// a row shared by both mapping nets (and, for aseg >= 0, by the alpha net as its segment aseg)
+AF_DEV void put_row(const PrepArgs& a, int seg, int aseg, int n, float x, float y, float t) {
+  const size_t r = (size_t)seg * a.N + n;
+  put_row_to(a.coords, a.x0_tile, r, x, y, t);
+  if (a.coords2) {
+    put_row_to(a.coords2, a.x0_tile2, r, x, y, t);
+    if (aseg >= 0) put_row_to(a.coordsA, nullptr, (size_t)aseg * a.N + n, x, y, t);
+  }
 }
 
 __global__ void k_prep(PrepArgs a) {
@@ -86,19 +96,23 @@ __global__ void k_prep(PrepArgs a) {
     const float ffu = r2[1], ffv = r2[2], fbu = r2[3], fbv = r3[0], mf = r3[1], mb = r3[2];
     const float hm = a.half_main, hg = a.half_grad, hf = a.half_frames;
     const float xc = (float)x / hm - 1.f, yc = (float)y / hm - 1.f, tc = (float)f / hf - 1.f;
-    put_row(a, 0, n, xc, yc, tc);
-    put_row(a, 1, n, (float)x / hg - 1.f, (float)(y + 1) / hg - 1.f, tc);
-    put_row(a, 2, n, (float)(x + 1) / hg - 1.f, (float)y / hg - 1.f, tc);
-    put_row(a, 3, n, xc, (float)(y - a.d_local) / hm - 1.f, tc);
-    put_row(a, 4, n, (float)(x - a.d_local) / hm - 1.f, yc, tc);
+    put_row(a, 0, 0, n, xc, yc, tc);
+    put_row(a, 1, 1, n, (float)x / hg - 1.f, (float)(y + 1) / hg - 1.f, tc);
+    put_row(a, 2, 2, n, (float)(x + 1) / hg - 1.f, (float)y / hg - 1.f, tc);
+    put_row(a, 3, -1, n, xc, (float)(y - a.d_local) / hm - 1.f, tc);
+    put_row(a, 4, -1, n, (float)(x - a.d_local) / hm - 1.f, yc, tc);
     vf = mf != 0.f; vb = mb != 0.f;
-    if (vf) put_row(a, 5, n, ((float)x + ffu) / hm - 1.f, ((float)y + ffv) / hm - 1.f, (float)(f + 1) / hf - 1.f);
-    else    put_row(a, 5, n, xc, yc, tc);
-    if (vb) put_row(a, 6, n, ((float)x + fbu) / hm - 1.f, ((float)y + fbv) / hm - 1.f, (float)(f - 1) / hf - 1.f);
-    else    put_row(a, 6, n, xc, yc, tc);
+    if (vf) put_row(a, 5, 3, n, ((float)x + ffu) / hm - 1.f, ((float)y + ffv) / hm - 1.f, (float)(f + 1) / hf - 1.f);
+    else    put_row(a, 5, 3, n, xc, yc, tc);
+    if (vb) put_row(a, 6, 4, n, ((float)x + fbu) / hm - 1.f, ((float)y + fbv) / hm - 1.f, (float)(f - 1) / hf - 1.f);
+    else    put_row(a, 6, 4, n, xc, yc, tc);
     if (a.nseg > 7) {
-      put_row(a, 7, n, xc, (float)(y - a.d_global) / hm - 1.f, tc);
-      put_row(a, 8, n, (float)(x - a.d_global) / hm - 1.f, yc, tc);
+      put_row_to(a.coords, a.x0_tile, (size_t)7 * a.N + n, xc, (float)(y - a.d_global) / hm - 1.f, tc);
+      put_row_to(a.coords, a.x0_tile, (size_t)8 * a.N + n, (float)(x - a.d_global) / hm - 1.f, yc, tc);
+      if (a.coords2) {
+        put_row_to(a.coords2, a.x0_tile2, (size_t)7 * a.N + n, xc, (float)(y - a.d_global2) / hm - 1.f, tc);
+        put_row_to(a.coords2, a.x0_tile2, (size_t)8 * a.N + n, (float)(x - a.d_global2) / hm - 1.f, yc, tc);
+      }
     }
   }
   const unsigned long long bf = __ballot(vf), bb = __ballot(vb);
@@ -224,10 +238,162 @@ __global__ __launch_bounds__(256) void k_loss_single(LossArgs a) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) s[i] = block_sum(s[i], red);
   if (threadIdx.x == 0) {
-    float* o = a.loss_part + (size_t)blockIdx.x * 8;
+    float* o = a.loss_part + (size_t)blockIdx.x * AF_LOSS_W;
 #pragma unroll
     for (int i = 0; i < 6; ++i) o[i] = s[i];
-    o[6] = 0.f; o[7] = 0.f;
+#pragma unroll
+    for (int i = 6; i < AF_LOSS_W; ++i) o[i] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss stack of the fg/bg dual-atlas path (stage1_neural_atlas_seg.py:210-311; loss_utils.py:173-224,
+// 227-278, 299-322, 385-408) + seed gradients wrt every output row of the four nets.
+AF_DEV float alpha_of(float t) { float a = 0.5f * (t + 1.f); a = a * 0.99f; return a + 0.001f; }   // :224-227
+#define AF_DALPHA 0.495f                                                                          // d alpha / d tanh-output
+
+__global__ __launch_bounds__(256) void k_loss_seg(LossSegArgs a) {
+  __shared__ float red[4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  float ls[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) ls[i] = 0.f;
+  if (n < a.N) {
+    const size_t N = a.N;
+    const float invN = 1.f / (float)a.N;
+    const float* sp = a.samples + (size_t)n * AF_REC_F;
+    // ---- alpha at the centre, the +1 neighbours and the flow matches
+    const float al = alpha_of(a.out_alpha[(size_t)n * 4]);
+    const float aly = alpha_of(a.out_alpha[(N + n) * 4]);
+    const float alx = alpha_of(a.out_alpha[(2 * N + n) * 4]);
+    float dA = 0.f, dAy = 0.f, dAx = 0.f, dAf = 0.f, dAb = 0.f;
+    // ---- colours: rgb = rgb1*alpha + rgb2*(1-alpha)  (:229-235), gradient loss (loss_utils.py:173-224), sparsity (:244,248)
+    const f32x4 t1c = *(const f32x4*)(a.out_atlas + (size_t)n * 4);
+    const f32x4 t1y = *(const f32x4*)(a.out_atlas + (N + n) * 4);
+    const f32x4 t1x = *(const f32x4*)(a.out_atlas + (2 * N + n) * 4);
+    const f32x4 t2c = *(const f32x4*)(a.out_atlas + (3 * N + n) * 4);
+    const f32x4 t2y = *(const f32x4*)(a.out_atlas + (4 * N + n) * 4);
+    const f32x4 t2x = *(const f32x4*)(a.out_atlas + (5 * N + n) * 4);
+    float d1c[3], d1y[3], d1x[3], d2c[3], d2y[3], d2x[3];
+    float sq1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float r1 = (t1c[c] + 1.f) * 0.5f, r2 = (t2c[c] + 1.f) * 0.5f;
+      const float r1y = (t1y[c] + 1.f) * 0.5f, r2y = (t2y[c] + 1.f) * 0.5f;
+      const float r1x = (t1x[c] + 1.f) * 0.5f, r2x = (t2x[c] + 1.f) * 0.5f;
+      const float rgb = r1 * al + r2 * (1.f - al);
+      const float rgby = r1y * aly + r2y * (1.f - aly);
+      const float rgbx = r1x * alx + r2x * (1.f - alx);
+      const float e = rgb - sp[REC_RGB + c];
+      const float rx = sp[REC_DX + c] - (rgbx - rgb), ry = sp[REC_DY + c] - (rgby - rgb);
+      const float nf = r1 * (1.f - al);
+      ls[0] += e * e;
+      ls[1] += rx * rx + ry * ry;
+      ls[13] += nf * nf;
+      sq1 += r1 * r1;
+      const float g = (a.c_rgb * 2.f * e + a.c_grad * 2.f * (rx + ry)) * invN;       // dL/d rgb
+      const float gx = -a.c_grad * 2.f * rx * invN, gy = -a.c_grad * 2.f * ry * invN;   // dL/d rgb(x+1), rgb(y+1)
+      // d/d tanh-output = 1/2 d/d rgb
+      d1c[c] = 0.5f * (al * g + a.c_sparse * 2.f * r1 * (1.f - al) * (1.f - al) * invN);
+      d2c[c] = 0.5f * (1.f - al) * g;
+      d1x[c] = 0.5f * alx * gx; d2x[c] = 0.5f * (1.f - alx) * gx;
+      d1y[c] = 0.5f * aly * gy; d2y[c] = 0.5f * (1.f - aly) * gy;
+      dA += (r1 - r2) * g;
+      dAx += (r1x - r2x) * gx;
+      dAy += (r1y - r2y) * gy;
+    }
+    dA -= a.c_sparse * 2.f * (1.f - al) * sq1 * invN;
+    { f32x4 v = {d1c[0], d1c[1], d1c[2], 0.f}; *(f32x4*)(a.dout_atlas + (size_t)n * 4) = v; }
+    { f32x4 v = {d1y[0], d1y[1], d1y[2], 0.f}; *(f32x4*)(a.dout_atlas + (N + n) * 4) = v; }
+    { f32x4 v = {d1x[0], d1x[1], d1x[2], 0.f}; *(f32x4*)(a.dout_atlas + (2 * N + n) * 4) = v; }
+    { f32x4 v = {d2c[0], d2c[1], d2c[2], 0.f}; *(f32x4*)(a.dout_atlas + (3 * N + n) * 4) = v; }
+    { f32x4 v = {d2y[0], d2y[1], d2y[2], 0.f}; *(f32x4*)(a.dout_atlas + (4 * N + n) * 4) = v; }
+    { f32x4 v = {d2x[0], d2x[1], d2x[2], 0.f}; *(f32x4*)(a.dout_atlas + (5 * N + n) * 4) = v; }
+    // ---- alpha bootstrapping, BCE against the (fractional) input mask (:301-302)
+    {
+      const float m = sp[REC_FG];
+      ls[12] = -m * logf(al) - (1.f - m) * logf(1.f - al);
+      dA += a.c_boot * (-m / al + (1.f - m) / (1.f - al)) * invN;
+    }
+    const float cntf = (float)a.counts[0], cntb = (float)a.counts[1];
+    const bool vf = sp[REC_MF] != 0.f, vb = sp[REC_MB] != 0.f;
+    // ---- alpha flow, L1 (loss_utils.py:385-408)
+    if (vf) {
+      const float d = al - alpha_of(a.out_alpha[(3 * N + n) * 4]);
+      ls[10] = fabsf(d);
+      const float g = a.c_aflow * 0.5f * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / cntf;
+      dA += g; dAf = -g;
+    }
+    if (vb) {
+      const float d = alpha_of(a.out_alpha[(4 * N + n) * 4]) - al;
+      ls[11] = fabsf(d);
+      const float g = a.c_aflow * 0.5f * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / cntb;
+      dAb = g; dA -= g;
+    }
+    // ---- the two mapping nets: rigidity (local, global) and alpha-weighted optical flow
+    const float fscale = a.L / (2.f * a.uv_scale);
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      const float* om = net ? a.out_m2 : a.out_m1;
+      float* dm = net ? a.dout_m2 : a.dout_m1;
+      const f32x4 uvc = *(const f32x4*)(om + (size_t)n * 4);
+      float du = 0.f, dv = 0.f;
+      put_d2(dm, N + n, 0.f, 0.f);        // (x,y+1) and (x+1,y) rows: gradient arrives from the atlas chain
+      put_d2(dm, 2 * N + n, 0.f, 0.f);
+      {
+        const f32x4 pym = *(const f32x4*)(om + (3 * N + n) * 4);
+        const f32x4 pxm = *(const f32x4*)(om + (4 * N + n) * 4);
+        const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale, (float)a.d_local, a.c_rig * invN);
+        ls[2 + net] = r.loss; du += r.du; dv += r.dv;
+        put_d2(dm, 3 * N + n, r.du_ym, r.dv_ym);
+        put_d2(dm, 4 * N + n, r.du_xm, r.dv_xm);
+      }
+      if (a.nseg > 7) {
+        const f32x4 pym = *(const f32x4*)(om + (7 * N + n) * 4);
+        const f32x4 pxm = *(const f32x4*)(om + (8 * N + n) * 4);
+        const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale,
+                               (float)(net ? a.d_global_bg : a.d_global_fg), (net ? a.c_grig_bg : a.c_grig_fg) * invN);
+        ls[4 + net] = r.loss; du += r.du; dv += r.dv;
+        put_d2(dm, 7 * N + n, r.du_ym, r.dv_ym);
+        put_d2(dm, 8 * N + n, r.du_xm, r.dv_xm);
+      }
+      const float wrow = net ? 1.f - al : al;        // flow rows are weighted by alpha (fg) / 1-alpha (bg), :285-293
+      const float wsign = net ? -1.f : 1.f;
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir) {
+        const bool valid = dir ? vb : vf;
+        const size_t row = (size_t)(5 + dir) * N + n;
+        float gu = 0.f, gv = 0.f;
+        if (valid) {
+          const f32x4 m = *(const f32x4*)(om + row * 4);
+          const float eu = m[0] - uvc[0], ev = m[1] - uvc[1];
+          const float nrm = sqrtf(eu * eu + ev * ev);
+          const float l = nrm * a.L / (2.f * a.uv_scale);
+          const float cnt = dir ? cntb : cntf;
+          ls[6 + 2 * net + dir] = l * wrow;
+          const float w = nrm > 0.f ? a.c_flow * 0.5f * fscale * wrow / (nrm * cnt) : 0.f;
+          gu = w * eu; gv = w * ev;
+          du -= gu; dv -= gv;
+          dA += wsign * a.c_flow * 0.5f * l / cnt;
+        }
+        put_d2(dm, row, gu, gv);
+      }
+      put_d2(dm, (size_t)n, du, dv);
+    }
+    // ---- alpha net seed gradients (tanh output -> alpha is affine with slope 0.495)
+    { f32x4 v = {AF_DALPHA * dA, 0.f, 0.f, 0.f};  *(f32x4*)(a.dout_alpha + (size_t)n * 4) = v; }
+    { f32x4 v = {AF_DALPHA * dAy, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (N + n) * 4) = v; }
+    { f32x4 v = {AF_DALPHA * dAx, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (2 * N + n) * 4) = v; }
+    { f32x4 v = {AF_DALPHA * dAf, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (3 * N + n) * 4) = v; }
+    { f32x4 v = {AF_DALPHA * dAb, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (4 * N + n) * 4) = v; }
+  }
+#pragma unroll
+  for (int i = 0; i < 14; ++i) ls[i] = block_sum(ls[i], red);
+  if (threadIdx.x == 0) {
+    float* o = a.loss_part + (size_t)blockIdx.x * AF_LOSS_W;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) o[i] = ls[i];
+    o[14] = 0.f; o[15] = 0.f;
   }
 }
 
@@ -259,7 +425,7 @@ __global__ __launch_bounds__(256) void k_pre_loss(PreLossArgs a) {
     put_d2(a.dout_map, (size_t)n, w * eu, w * ev);
   }
   l = block_sum(l, red);
-  if (threadIdx.x == 0) { float* o = a.loss_part + (size_t)blockIdx.x * 8; o[0] = l; for (int i = 1; i < 8; ++i) o[i] = 0.f; }
+  if (threadIdx.x == 0) { float* o = a.loss_part + (size_t)blockIdx.x * AF_LOSS_W; o[0] = l; for (int i = 1; i < AF_LOSS_W; ++i) o[i] = 0.f; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,13 +472,13 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   }
   if (UPDATE && blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {
     // fold the per-block loss partials of this step (fixed order); report and reset the flow counters
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < AF_LOSS_W - 2) {
       float s = 0.f;
-      for (int b = 0; b < a.loss_nblk; ++b) s += a.loss_part[b * 8 + threadIdx.x];
+      for (int b = 0; b < a.loss_nblk; ++b) s += a.loss_part[b * AF_LOSS_W + threadIdx.x];
       a.loss_out[threadIdx.x] = s;
-    } else if (threadIdx.x < 8) {
-      a.loss_out[threadIdx.x] = (float)a.counts[threadIdx.x - 6];
-      a.counts[threadIdx.x - 6] = 0;
+    } else if (threadIdx.x < AF_LOSS_W) {
+      a.loss_out[threadIdx.x] = (float)a.counts[threadIdx.x - (AF_LOSS_W - 2)];
+      a.counts[threadIdx.x - (AF_LOSS_W - 2)] = 0;
     }
   }
 }
@@ -352,8 +518,44 @@ __global__ __launch_bounds__(256) void k_frame_finish(const float* out_atlas, co
   if (threadIdx.x == 0) sse_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// fg/bg path (evaluate.py:302-337): rgb = rgb1*alpha + rgb2*(1-alpha); out_atlas holds the fg rows then,
+// `row2` rows later, the bg rows.
+__global__ __launch_bounds__(256) void k_frame_finish_seg(const float* out_atlas, const float* out_alpha, size_t row2, const float* table,
+                                                         float* rgb_out, double* sse_part, int npix, size_t rec0) {
+  __shared__ double red[4];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  double sse = 0.0;
+  if (r < npix) {
+    const f32x4 t1 = *(const f32x4*)(out_atlas + (size_t)r * 4);
+    const f32x4 t2 = *(const f32x4*)(out_atlas + (row2 + r) * 4);
+    const float al = alpha_of(out_alpha[(size_t)r * 4]);
+    const float* rec = table + (rec0 + r) * AF_REC_F;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = ((t1[c] + 1.f) * 0.5f) * al + ((t2[c] + 1.f) * 0.5f) * (1.f - al);
+      rgb_out[(size_t)r * 3 + c] = v;
+      const double d = (double)rec[REC_RGB + c] - (double)v;
+      sse += d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
+  __syncthreads();
+  if (threadIdx.x == 0) sse_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+int af_launch_loss_seg(const LossSegArgs* a, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_seg, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_frame_finish_seg(const float* out_atlas, const float* out_alpha, size_t row2, const float* table, float* rgb_out, double* sse_part,
+                               int npix, size_t rec0, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_finish_seg, dim3((npix + 255) / 256), dim3(256), 0, s, out_atlas, out_alpha, row2, table, rgb_out, sse_part, npix, rec0);
+  return (int)hipGetLastError();
+}
 int af_launch_pack(const PackArgs* a, hipStream_t s) {
   const size_t n = (size_t)a->resx * a->resy * a->F;
   hipLaunchKernelGGL(k_pack_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);

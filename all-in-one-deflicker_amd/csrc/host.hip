@@ -1,6 +1,8 @@
 // host.hip — handle, memory plan, dW schedule and the C ABI of libatlasfit.so (include/atlasfit.h).
 // The per-iteration loop body of the reference (src/stage1_neural_atlas.py:151-231) becomes eight kernel
 // launches on one stream: prep -> mapping fwd -> atlas fwd -> loss -> atlas bwd -> mapping bwd -> dW -> adam.
+// The fg/bg dual-atlas loop (src/stage1_neural_atlas_seg.py:191-315) is the same chain over four nets:
+// prep -> fwd {mapping1, mapping2, alpha, atlas} -> loss -> bwd {atlas, mapping1, mapping2, alpha} -> dW -> adam.
 // No host synchronisation inside the loop; the host only enqueues.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -23,6 +25,9 @@ int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
 int af_launch_prep(const PrepArgs* a, hipStream_t s);
 int af_launch_loss_single(const LossArgs* a, hipStream_t s);
+int af_launch_loss_seg(const LossSegArgs* a, hipStream_t s);
+int af_launch_frame_finish_seg(const float* out_atlas, const float* out_alpha, size_t row2, const float* table, float* rgb_out, double* sse_part,
+                               int npix, size_t rec0, hipStream_t s);
 int af_launch_pre_prep(const PrePrepArgs* a, hipStream_t s);
 int af_launch_pre_loss(const PreLossArgs* a, hipStream_t s);
 int af_launch_adam(const AdamArgs* a, int njobs, int update, hipStream_t s);
@@ -48,6 +53,7 @@ struct NetDesc {
   AfChunk *d_fchunks = nullptr, *d_bchunks = nullptr;
   // activations
   int nt_cap = 0;
+  float *coords = nullptr, *x0_tile = nullptr;         // input rows [rows_pad][4] (+ T-layout copy for the layer-0 dW of xyt nets)
   float *acts = nullptr, *dz = nullptr, *dz_last = nullptr, *pe_tile = nullptr, *out_buf = nullptr, *dout = nullptr;
   uint32_t* masks = nullptr;
 };
@@ -64,8 +70,8 @@ struct TimedEv { int cls; hipEvent_t a, b; };
 
 struct af_handle {
   af_config cfg;
-  int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; int ncu = 256;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = false;
+  bool seg = false;                   // two_layer: four nets (stage1_neural_atlas_seg.py), else two
+  int device = 0; hipStream_t stream = nullptr; int ncu = 256;
   std::string err;
   NetDesc nets[AF_MAX_NETS];
   size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0;
@@ -75,17 +81,17 @@ struct af_handle {
   // video
   float* table = nullptr; bool have_video = false;
   // batch
-  int N = 0, rows_cap_map = 0, rows_cap_atlas = 0;
-  float *coords = nullptr, *x0_tile = nullptr, *samples = nullptr, *loss_part = nullptr, *loss_log = nullptr;
-  int* counts = nullptr; int loss_nblk = 0; size_t loss_log_cap = 0;
+  int N = 0;
+  float *samples = nullptr, *loss_part = nullptr, *loss_log = nullptr;
+  int* counts = nullptr; int loss_nblk_cap = 0; size_t loss_log_cap = 0;
   int cur_nseg = 0;
-  // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain map1, 3 = pretrain map2
+  // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
   Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
   // render
-  int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
+  int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
-  std::vector<TimedEv> evs; double t_ms[8] = {0}; long long t_cnt[8] = {0};
+  std::vector<TimedEv> evs; double t_ms[16] = {0}; long long t_cnt[16] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
     char buf[512];
@@ -100,6 +106,14 @@ struct af_handle {
 #define LCHK(x) do { int r_ = (x); if (r_ != 0) return h->fail(AF_EHIP, #x, (hipError_t)r_); } while (0)
 
 namespace {
+
+// timing classes (include/atlasfit.h: af_get_timing)
+enum { T_PREP = 0, T_FWD_MAP1 = 1, T_FWD_ATLAS = 2, T_LOSS = 3, T_BWD_ATLAS = 4, T_BWD_MAP1 = 5, T_DW = 6, T_ADAM = 7,
+       T_FWD_MAP2 = 8, T_FWD_ALPHA = 9, T_BWD_MAP2 = 10, T_BWD_ALPHA = 11 };
+const int kFwdClass[AF_MAX_NETS] = {T_FWD_MAP1, T_FWD_ATLAS, T_FWD_MAP2, T_FWD_ALPHA};
+const int kBwdClass[AF_MAX_NETS] = {T_BWD_MAP1, T_BWD_ATLAS, T_BWD_MAP2, T_BWD_ALPHA};
+// algorithmic fwd + dX + dW FLOPs per MLP row (BASELINE.md §3 / SURVEY.md §8d), indexed by af_net
+const double kFlopRow[AF_MAX_NETS] = {1579008.0, 2466784.0, 792576.0, 2391552.0};
 
 template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
@@ -170,7 +184,7 @@ int shape_tiles(int shape, int& To, int& Ti) {
 struct NetUse { NetDesc* n; int NT; };
 
 // Build the dW job list, the Adam job list and the cost-balanced split-K schedule for a set of nets.
-bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses, float* x0_tile) {
+bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   sc.jobs.clear(); sc.ajobs.clear(); sc.segs.clear();
   std::vector<int> job_nt;
   auto add = [&](NetDesc& n, int NT, int l, int shape, const float* A, uint32_t as, const float* B, uint32_t bs,
@@ -196,7 +210,7 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses, float
     for (int l = 0; l < n.NL; ++l) {
       const bool last = l == n.NL - 1, sk = (n.skip >> l) & 1;
       if (l == 0) {
-        if (n.in_kind == AF_IN_XYT) add(n, NT, 0, DW_8x1, n.dz, AF_TILE_F, x0_tile, 1024, 0, 3, true);
+        if (n.in_kind == AF_IN_XYT) add(n, NT, 0, DW_8x1, n.dz, AF_TILE_F, n.x0_tile, 1024, 0, 3, true);
         else                        add(n, NT, 0, DW_8x2, n.dz, AF_TILE_F, n.pe_tile, 2048, 0, n.pe_feats, true);
       } else if (!last) {
         add(n, NT, l, DW_8x8, n.dz + l * ts, AF_TILE_F, n.acts + (l - 1) * ts, AF_TILE_F, 0, AF_HID, true);
@@ -266,7 +280,7 @@ hipError_t upload_sched(Sched& sc) {
 
 int tiles_of(int rows) { return (rows + 31) / 32; }
 
-hipError_t alloc_net_buffers(NetDesc& n, int rows_cap) {
+hipError_t alloc_net_buffers(NetDesc& n, int rows_cap, bool own_coords) {
   n.nt_cap = tiles_of(rows_cap);
   const size_t nt = n.nt_cap, rp = nt * 32;
   hipError_t e;
@@ -280,18 +294,28 @@ hipError_t alloc_net_buffers(NetDesc& n, int rows_cap) {
   if ((e = hipMemset(n.dz_last, 0, nt * 1024 * 4)) != hipSuccess) return e;
   if (n.pe_feats && (e = hipMemset(n.pe_tile, 0, nt * 2048 * 4)) != hipSuccess) return e;
   if ((e = hipMemset(n.out_buf, 0, rp * 16)) != hipSuccess) return e;
-  return hipMemset(n.dout, 0, rp * 16);
+  if ((e = hipMemset(n.dout, 0, rp * 16)) != hipSuccess) return e;
+  if (own_coords) {
+    if ((e = dalloc(&n.coords, rp * 4)) != hipSuccess) return e;
+    if ((e = hipMemset(n.coords, 0, rp * 16)) != hipSuccess) return e;
+    if (n.in_kind == AF_IN_XYT) {
+      if ((e = dalloc(&n.x0_tile, nt * 1024)) != hipSuccess) return e;
+      if ((e = hipMemset(n.x0_tile, 0, nt * 4096)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
 }
 
 void free_net(NetDesc& n) {
   (void)hipFree(n.acts); (void)hipFree(n.dz); (void)hipFree(n.masks); (void)hipFree(n.dz_last); (void)hipFree(n.pe_tile); (void)hipFree(n.out_buf); (void)hipFree(n.dout);
+  (void)hipFree(n.coords); (void)hipFree(n.x0_tile);
   (void)hipFree(n.d_fchunks); (void)hipFree(n.d_bchunks);
 }
 
 FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train) {
   FwdArgs a{};
   a.wimg = h->img_f + n.f_base; a.chunks = n.d_fchunks; a.bias = h->bias_img + n.bias_base;
-  a.in = in; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
+  a.in = in; a.in1 = nullptr; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
   a.NT = NT; a.nt_stride = NT; a.nchunks = (int)n.fchunks.size();
   return a;
@@ -316,9 +340,9 @@ struct Timer {
 
 void drain_timers(af_handle* h) {
   for (TimedEv& e : h->evs) {
-    float ms = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&ms, e.a, e.b);
+    float ms = 0; (void)hipEventSynchronize(e.b); (void)hipEventElapsedTime(&ms, e.a, e.b);
     h->t_ms[e.cls] += ms; h->t_cnt[e.cls] += 1;
-    hipEventDestroy(e.a); hipEventDestroy(e.b);
+    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
   }
   h->evs.clear();
 }
@@ -332,15 +356,6 @@ AdamHyper adam_hyper(double lr, long long step) {
   return hy;
 }
 
-int ensure_partial(af_handle* h, size_t floats) {
-  if (floats <= h->partial_cap) return 0;
-  if (h->partial) (void)hipFree(h->partial);
-  h->partial = nullptr; h->partial_cap = 0;
-  HCHK(dalloc(&h->partial, floats));
-  h->partial_cap = floats;
-  return 0;
-}
-
 // re-emit the GEMM weight views of the jobs of a schedule from the canonical parameters
 int repack(af_handle* h, Sched& sc) {
   AdamArgs a{};
@@ -350,10 +365,153 @@ int repack(af_handle* h, Sched& sc) {
   return 0;
 }
 
+bool glob_on(const af_config& c, int iter) { return c.include_global_rigidity_loss && iter <= c.stop_global_rigidity; }
+
+int launch_fwd(af_handle* h, int net, const FwdArgs& fa, bool train) {
+  Timer t(h, kFwdClass[net]);
+  LCHK(af_launch_fwd(net, train ? 1 : 0, &fa, h->stream));
+  return 0;
+}
+int launch_bwd(af_handle* h, int net, const BwdArgs& ba) {
+  Timer t(h, kBwdClass[net]);
+  LCHK(af_launch_bwd(net, &ba, h->stream));
+  return 0;
+}
+
+// dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
+int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk) {
+  { Timer t(h, T_DW); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
+  {
+    Timer t(h, T_ADAM);
+    AdamArgs a{};
+    a.jobs = sc.d_ajobs; a.partial = h->partial;
+    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img};
+    a.hy = adam_hyper(h->cfg.lr, step);
+    a.grad_out = h->debug ? h->grads : nullptr;
+    a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = loss_nblk;
+    LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 1, h->stream));
+  }
+  return 0;
+}
+
+int ensure_loss_log(af_handle* h, size_t steps) {
+  if (steps * AF_LOSS_W <= h->loss_log_cap) return 0;
+  if (h->loss_log) (void)hipFree(h->loss_log);
+  h->loss_log = nullptr; h->loss_log_cap = 0;
+  HCHK(dalloc(&h->loss_log, steps * AF_LOSS_W));
+  h->loss_log_cap = steps * AF_LOSS_W;
+  return 0;
+}
+
+// One iteration of the single-atlas loop (stage1_neural_atlas.py:159-231), enqueued on the handle's stream.
+int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, float* loss_out) {
+  const af_config& c = h->cfg;
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
+  const int N = h->N, L = std::max(c.resx, c.resy);
+  const bool glob = glob_on(c, i);
+  const int nseg = glob ? 9 : 7;
+  Sched& sc = h->sched[glob ? 0 : 1];
+  const int NT_map = tiles_of(nseg * N), NT_atlas = tiles_of(3 * N);
+  if (nseg != h->cur_nseg) {   // pad rows of the last tile must carry zero gradient
+    HCHK(hipMemsetAsync(M.dout, 0, (size_t)M.nt_cap * 32 * 16, h->stream));
+    h->cur_nseg = nseg;
+  }
+  {
+    Timer t(h, T_PREP);
+    PrepArgs p{};
+    p.table = h->table; p.inds = d_inds; p.seed = seed; p.iter = (uint32_t)i;
+    p.N = N; p.resx = c.resx; p.resy = c.resy; p.F = c.number_of_frames;
+    p.half_main = (float)(L / 2.0); p.half_grad = (float)(c.resx / 2.0); p.half_frames = (float)(c.number_of_frames / 2.0);
+    p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
+    p.coords = M.coords; p.x0_tile = M.x0_tile; p.samples = h->samples; p.counts = h->counts;
+    LCHK(af_launch_prep(&p, h->stream));
+  }
+  int rc;
+  if ((rc = launch_fwd(h, AF_NET_MAP1, fwd_args(h, M, M.coords, M.out_buf, NT_map, true), true)) != 0) return rc;
+  if ((rc = launch_fwd(h, AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true), true)) != 0) return rc;
+  {
+    Timer t(h, T_LOSS);
+    LossArgs l{};
+    l.samples = h->samples; l.out_map = M.out_buf; l.out_atlas = A.out_buf; l.dout_map = M.dout; l.dout_atlas = A.dout;
+    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
+    l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount; l.d_global = c.global_rigidity_derivative_amount_fg;
+    l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
+    l.c_grig = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_flow = c.optical_flow_coeff;
+    LCHK(af_launch_loss_single(&l, h->stream));
+  }
+  h->adam_step += 1;
+  { BwdArgs b = bwd_args(h, A, NT_atlas); b.din0 = M.dout; b.nrows = 3 * N; if ((rc = launch_bwd(h, AF_NET_ATLAS, b)) != 0) return rc; }
+  if ((rc = launch_bwd(h, AF_NET_MAP1, bwd_args(h, M, NT_map))) != 0) return rc;
+  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256);
+}
+
+// One iteration of the fg/bg dual-atlas loop (stage1_neural_atlas_seg.py:193-315).
+int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, float* loss_out) {
+  const af_config& c = h->cfg;
+  NetDesc& M1 = h->nets[AF_NET_MAP1]; NetDesc& M2 = h->nets[AF_NET_MAP2]; NetDesc& A = h->nets[AF_NET_ATLAS]; NetDesc& AL = h->nets[AF_NET_ALPHA];
+  const int N = h->N, L = std::max(c.resx, c.resy);
+  const bool glob = glob_on(c, i);
+  const int nseg = glob ? 9 : 7;
+  Sched& sc = h->sched[glob ? 0 : 1];
+  const int NT_map = tiles_of(nseg * N), NT_atlas = tiles_of(6 * N), NT_alpha = tiles_of(5 * N);
+  if (nseg != h->cur_nseg) {
+    HCHK(hipMemsetAsync(M1.dout, 0, (size_t)M1.nt_cap * 32 * 16, h->stream));
+    HCHK(hipMemsetAsync(M2.dout, 0, (size_t)M2.nt_cap * 32 * 16, h->stream));
+    h->cur_nseg = nseg;
+  }
+  {
+    Timer t(h, T_PREP);
+    PrepArgs p{};
+    p.table = h->table; p.inds = d_inds; p.seed = seed; p.iter = (uint32_t)i;
+    p.N = N; p.resx = c.resx; p.resy = c.resy; p.F = c.number_of_frames;
+    p.half_main = (float)(L / 2.0); p.half_grad = (float)(c.resx / 2.0); p.half_frames = (float)(c.number_of_frames / 2.0);
+    p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
+    p.coords = M1.coords; p.x0_tile = M1.x0_tile; p.samples = h->samples; p.counts = h->counts;
+    p.coords2 = M2.coords; p.x0_tile2 = M2.x0_tile; p.coordsA = AL.coords; p.d_global2 = c.global_rigidity_derivative_amount_bg;
+    LCHK(af_launch_prep(&p, h->stream));
+  }
+  int rc;
+  if ((rc = launch_fwd(h, AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true), true)) != 0) return rc;
+  if ((rc = launch_fwd(h, AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true), true)) != 0) return rc;
+  if ((rc = launch_fwd(h, AF_NET_ALPHA, fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true), true)) != 0) return rc;
+  {   // atlas rows: [0,3N) = uv1*0.5+0.5 (foreground quadrant), [3N,6N) = uv2*0.5-0.5 (background), :229-232
+    FwdArgs fa = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true);
+    fa.in1 = M2.out_buf; fa.split_row = 3 * N;
+    if ((rc = launch_fwd(h, AF_NET_ATLAS, fa, true)) != 0) return rc;
+  }
+  {
+    Timer t(h, T_LOSS);
+    LossSegArgs l{};
+    l.samples = h->samples; l.out_m1 = M1.out_buf; l.out_m2 = M2.out_buf; l.out_alpha = AL.out_buf; l.out_atlas = A.out_buf;
+    l.dout_m1 = M1.dout; l.dout_m2 = M2.dout; l.dout_alpha = AL.dout; l.dout_atlas = A.dout;
+    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
+    l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount;
+    l.d_global_fg = c.global_rigidity_derivative_amount_fg; l.d_global_bg = c.global_rigidity_derivative_amount_bg;
+    l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
+    l.c_grig_fg = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_grig_bg = glob ? c.global_rigidity_coeff_bg : 0.f;
+    l.c_flow = c.optical_flow_coeff;
+    l.c_boot = i > c.stop_bootstrapping_iteration ? 0.f : c.alpha_bootstrapping_factor;     // :193-194
+    l.c_aflow = c.alpha_flow_factor; l.c_sparse = c.sparsity_coeff;
+    LCHK(af_launch_loss_seg(&l, h->stream));
+  }
+  h->adam_step += 1;
+  {
+    BwdArgs b = bwd_args(h, A, NT_atlas);
+    b.din0 = M1.dout; b.din1 = M2.dout; b.split_row = 3 * N; b.nrows = 6 * N;
+    if ((rc = launch_bwd(h, AF_NET_ATLAS, b)) != 0) return rc;
+  }
+  if ((rc = launch_bwd(h, AF_NET_MAP1, bwd_args(h, M1, NT_map))) != 0) return rc;
+  if ((rc = launch_bwd(h, AF_NET_MAP2, bwd_args(h, M2, NT_map))) != 0) return rc;
+  if ((rc = launch_bwd(h, AF_NET_ALPHA, bwd_args(h, AL, NT_alpha))) != 0) return rc;
+  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256);
+}
+
 }  // namespace
 
 // =================================================================================================
 extern "C" {
+
+size_t af_config_size(void) { return sizeof(af_config); }
 
 const char* af_last_error(const af_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -369,28 +527,33 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (cfg->use_positional_encoding_mapping1) return bad("use_positional_encoding_mapping1=true is not built");
   if (!cfg->use_gradient_loss) return bad("use_gradient_loss=false is not built");
   if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
+  const bool seg = cfg->two_layer != 0;
+  if (seg) {
+    if (cfg->number_of_channels_mapping2 != AF_HID || cfg->number_of_channels_alpha != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:21,26)");
+    if (cfg->number_of_layers_mapping2 != 4 || cfg->number_of_layers_alpha != 8) return bad("only 4-layer mapping2 / 8-layer alpha nets are built (config_flow_100.json:22,27)");
+    if (cfg->positional_encoding_num_alpha != 5) return bad("positional_encoding_num_alpha must be 5");
+    if (cfg->use_positional_encoding_mapping2) return bad("use_positional_encoding_mapping2=true is not built");
+    if (cfg->global_rigidity_derivative_amount_bg <= 0) return bad("global_rigidity_derivative_amount_bg");
+  }
   hipError_t e = hipSetDevice(device_ordinal);
   if (e != hipSuccess) { g_create_error = std::string("af_create: hipSetDevice: ") + hipGetErrorString(e); return AF_EHIP; }
   af_handle* h = new af_handle();
-  h->cfg = *cfg; h->device = device_ordinal;
+  h->cfg = *cfg; h->device = device_ordinal; h->seg = seg;
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
   auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
 #define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->fail(AF_EHIP, #x, e_); return die(e_ == hipErrorOutOfMemory ? AF_ENOMEM : AF_EHIP); } } while (0)
   hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
   h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  {   // main stream = critical path (high priority); stream2 = filler work (low priority)
-    int lo = 0, hi = 0; CCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi)); CCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo));
-  }
-  CCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); CCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  // Two-stream overlap of the atlas-independent mapping rows: measured SLOWER on MI355X (2.01 vs 1.97 ms/step,
-  // profiles/r1_overlap_timeline.txt: the hardware packs the co-running kernels poorly), so it is opt-in.
-  if (const char* e = getenv("AF_OVERLAP")) h->overlap = (e[0] == '1');
+  CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_dw_init());
 
   describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
   describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
+  if (seg) {
+    describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, 4, AF_IN_XYT, 0, 2, 0u, false);
+    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, 8, AF_IN_PE3, 5, 1, 0u, false);
+  }
   size_t fc = 0, bc = 0, biasc = 0, pc = 0;
   for (NetDesc& n : h->nets) if (n.used) { n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc); }
   fc += AF_CHUNK_MAX / 4; bc += AF_CHUNK_MAX / 4;   // every LDS stage copies a full 64 KB buffer: keep the over-read in bounds
@@ -408,25 +571,32 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   }
   // batch buffers
   h->N = cfg->samples_batch;
-  const int rows_full = 9 * h->N, rows_pre = h->cfg.pretrain_batch;
-  h->rows_cap_map = std::max(rows_full, rows_pre);
-  h->rows_cap_atlas = 3 * h->N;
-  CCHK(alloc_net_buffers(h->nets[AF_NET_MAP1], h->rows_cap_map));
-  CCHK(alloc_net_buffers(h->nets[AF_NET_ATLAS], h->rows_cap_atlas));
-  const size_t ntm = tiles_of(h->rows_cap_map);
-  CCHK(dalloc(&h->coords, ntm * 32 * 4)); CCHK(hipMemset(h->coords, 0, ntm * 32 * 16));
-  CCHK(dalloc(&h->x0_tile, ntm * 1024)); CCHK(hipMemset(h->x0_tile, 0, ntm * 4096));
-  CCHK(dalloc(&h->samples, (size_t)h->N * AF_REC_F));
-  h->loss_nblk = (std::max(h->N, rows_pre) + 255) / 256;
-  CCHK(dalloc(&h->loss_part, (size_t)h->loss_nblk * 8)); CCHK(hipMemset(h->loss_part, 0, (size_t)h->loss_nblk * 32));
+  const int N = h->N, rows_pre = h->cfg.pretrain_batch;
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS]; NetDesc& M2 = h->nets[AF_NET_MAP2]; NetDesc& AL = h->nets[AF_NET_ALPHA];
+  CCHK(alloc_net_buffers(M, std::max(9 * N, rows_pre), true));
+  CCHK(alloc_net_buffers(A, (seg ? 6 : 3) * N, false));
+  if (seg) {
+    CCHK(alloc_net_buffers(M2, std::max(9 * N, rows_pre), true));
+    CCHK(alloc_net_buffers(AL, 5 * N, true));
+  }
+  CCHK(dalloc(&h->samples, (size_t)N * AF_REC_F));
+  h->loss_nblk_cap = (std::max(N, rows_pre) + 255) / 256;
+  CCHK(dalloc(&h->loss_part, (size_t)h->loss_nblk_cap * AF_LOSS_W)); CCHK(hipMemset(h->loss_part, 0, (size_t)h->loss_nblk_cap * AF_LOSS_W * 4));
   CCHK(dalloc(&h->counts, 2)); CCHK(hipMemset(h->counts, 0, 8));
   // schedules
-  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
-  if (!build_sched(h, h->sched[0], {{&M, tiles_of(9 * h->N)}, {&A, tiles_of(3 * h->N)}}, h->x0_tile) ||
-      !build_sched(h, h->sched[1], {{&M, tiles_of(7 * h->N)}, {&A, tiles_of(3 * h->N)}}, h->x0_tile) ||
-      !build_sched(h, h->sched[2], {{&M, tiles_of(rows_pre)}}, h->x0_tile)) { h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup"); return die(AF_EINVAL); }
+  bool ok = true;
+  for (int v = 0; v < 2 && ok; ++v) {
+    const int nseg = v == 0 ? 9 : 7;
+    std::vector<NetUse> uses = {{&M, tiles_of(nseg * N)}};
+    if (seg) { uses.push_back({&M2, tiles_of(nseg * N)}); uses.push_back({&AL, tiles_of(5 * N)}); }
+    uses.push_back({&A, tiles_of((seg ? 6 : 3) * N)});
+    ok = build_sched(h, h->sched[v], uses);
+  }
+  ok = ok && build_sched(h, h->sched[2], {{&M, tiles_of(rows_pre)}});
+  if (seg) ok = ok && build_sched(h, h->sched[3], {{&M2, tiles_of(rows_pre)}});
+  if (!ok) { h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup"); return die(AF_EINVAL); }
   size_t pf = 0;
-  for (int i = 0; i < 3; ++i) { CCHK(upload_sched(h->sched[i])); pf = std::max(pf, h->sched[i].partial_floats); }
+  for (int i = 0; i < (seg ? 4 : 3); ++i) { CCHK(upload_sched(h->sched[i])); pf = std::max(pf, h->sched[i].partial_floats); }
   CCHK(dalloc(&h->partial, pf)); h->partial_cap = pf;
   h->frame_sse.assign(cfg->number_of_frames, 0.0); h->frame_sse_valid.assign(cfg->number_of_frames, 0);
   if (repack(h, h->sched[0]) != 0) return die(AF_EHIP);
@@ -438,18 +608,16 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
 
 void af_destroy(af_handle* h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   drain_timers(h);
   for (NetDesc& n : h->nets) if (n.used) free_net(n);
   for (Sched& s : h->sched) { (void)hipFree(s.d_jobs); (void)hipFree(s.d_ajobs); (void)hipFree(s.d_segs); }
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
   (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table);
-  (void)hipFree(h->coords); (void)hipFree(h->x0_tile); (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
-  (void)hipFree(h->partial); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
+  (void)hipFree(h->partial); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
+  (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -464,6 +632,7 @@ int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, co
                     const float* mask_fwd, const float* mask_bwd, const float* mask_fg, int on_device) {
   if (!h) return AF_EINVAL;
   if (!frames || !flow_fwd || !flow_bwd || !mask_fwd || !mask_bwd) return h->fail(AF_EINVAL, "af_upload_video: null tensor");
+  if (h->seg && !mask_fg) return h->fail(AF_EINVAL, "af_upload_video: a two_layer handle needs mask_fg (mask_frames, unwrap_utils.py:68-70)");
   HCHK(hipSetDevice(h->device));
   const size_t P2 = (size_t)h->cfg.resx * h->cfg.resy, F = h->cfg.number_of_frames, P = P2 * F;
   if (!h->table) { hipError_t e = dalloc(&h->table, P * AF_REC_F); if (e != hipSuccess) return h->fail(AF_ENOMEM, "record table", e); }
@@ -547,11 +716,11 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
 }
 
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
-int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFu; return AF_OK; }
-int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset) {
+int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
+int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, int reset) {
   if (!h) return AF_EINVAL;
-  hipSetDevice(h->device); hipStreamSynchronize(h->stream); drain_timers(h);
-  for (int i = 0; i < 8; ++i) { if (ms8) ms8[i] = h->t_ms[i]; if (counts8) counts8[i] = h->t_cnt[i]; if (reset) { h->t_ms[i] = 0; h->t_cnt[i] = 0; } }
+  (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); drain_timers(h);
+  for (int i = 0; i < 16; ++i) { if (ms16) ms16[i] = h->t_ms[i]; if (counts16) counts16[i] = h->t_cnt[i]; if (reset) { h->t_ms[i] = 0; h->t_cnt[i] = 0; } }
   return AF_OK;
 }
 
@@ -562,70 +731,18 @@ int af_get_last_grads(af_handle* h, int net, float* flat, size_t n) {
   return AF_OK;
 }
 
-static int ensure_loss_log(af_handle* h, size_t steps) {
-  if (steps * 8 <= h->loss_log_cap) return 0;
-  if (h->loss_log) (void)hipFree(h->loss_log);
-  h->loss_log = nullptr; h->loss_log_cap = 0;
-  HCHK(dalloc(&h->loss_log, steps * 8));
-  h->loss_log_cap = steps * 8;
-  return 0;
-}
-
-// One backward + update tail shared by the main loop and the pre-train: chains, dW, Adam.
-// The mapping rows that do not feed the atlas (row tiles >= tiles_of(3N): rigidity and flow rows) are
-// independent of the atlas kernels, so their forward / backward launches go to a second stream and fill the
-// CUs the atlas kernels and the kernel tails leave idle.  fork(): stream2 waits for everything enqueued on
-// the main stream so far; join(): the main stream waits for stream2.
-static int fork_streams(af_handle* h) {
-  HCHK(hipEventRecord(h->ev_fork, h->stream)); HCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-  return 0;
-}
-static int join_streams(af_handle* h) {
-  HCHK(hipEventRecord(h->ev_join, h->stream2)); HCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-  return 0;
-}
-
-// One backward + update tail shared by the main loop and the pre-train: chains, dW, Adam.
-static int step_tail(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, bool with_atlas, int NT_map, int NT_atlas, int rows_atlas) {
-  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
-  const bool split = with_atlas && h->overlap && NT_atlas < NT_map;
-  if (split) { int rc = fork_streams(h); if (rc) return rc; }
-  if (with_atlas) {
-    Timer t(h, 4);
-    BwdArgs b = bwd_args(h, A, NT_atlas);
-    b.din0 = M.dout; b.nrows = rows_atlas;
-    LCHK(af_launch_bwd(AF_NET_ATLAS, &b, h->stream));
-  }
-  if (split) {
-    BwdArgs b = bwd_args(h, M, NT_map); b.tile0 = NT_atlas;
-    LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream2));
-  }
-  { Timer t(h, 5); BwdArgs b = bwd_args(h, M, NT_map); if (split) b.NT = NT_atlas; LCHK(af_launch_bwd(AF_NET_MAP1, &b, h->stream)); }
-  if (split) { int rc = join_streams(h); if (rc) return rc; }
-  { Timer t(h, 6); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
-  {
-    Timer t(h, 7);
-    AdamArgs a{};
-    a.jobs = sc.d_ajobs; a.partial = h->partial;
-    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img};
-    a.hy = adam_hyper(h->cfg.lr, step);
-    a.grad_out = h->debug ? h->grads : nullptr;
-    a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = (h->N + 255) / 256;
-    LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 1, h->stream));
-  }
-  return 0;
-}
+int af_loss_width(const af_handle* h) { return h && h->seg ? 16 : 8; }
 
 int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, const int64_t* xs, uint64_t seed, float* losses_out) {
   if (!h) return AF_EINVAL;
-  if (net != AF_MAPPING1) return h->fail(AF_EINVAL, "af_pretrain: only AF_MAPPING1 is built in this configuration");
+  if (!(net == AF_MAPPING1 || (net == AF_MAPPING2 && h->seg))) return h->fail(AF_EINVAL, "af_pretrain: net must be a mapping net of this handle");
   if (pretrain_iters < 0 || ((ys == nullptr) != (xs == nullptr))) return h->fail(AF_EINVAL, "af_pretrain: arguments");
   HCHK(hipSetDevice(h->device));
   const int F = h->cfg.number_of_frames, NB = h->cfg.pretrain_batch;
   const size_t steps = (size_t)pretrain_iters * F;
   if (steps == 0) return AF_OK;
-  NetDesc& M = h->nets[AF_NET_MAP1];
-  Sched& sc = h->sched[2];
+  NetDesc& M = h->nets[net];
+  Sched& sc = h->sched[net == AF_MAPPING1 ? 2 : 3];
   int rc = ensure_loss_log(h, steps); if (rc) return rc;
   int64_t *d_ys = nullptr, *d_xs = nullptr;
   if (ys) {
@@ -635,11 +752,10 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
   }
   const int NT = tiles_of(NB);
   HCHK(hipMemsetAsync(M.dout, 0, (size_t)M.nt_cap * 32 * 16, h->stream));
-  HCHK(hipMemsetAsync(h->pre_m, 0, h->total_params * 4, h->stream));
+  HCHK(hipMemsetAsync(h->pre_m, 0, h->total_params * 4, h->stream));     // pre_train_mapping builds its own Adam (unwrap_utils.py:178)
   HCHK(hipMemsetAsync(h->pre_v, 0, h->total_params * 4, h->stream));
   h->cur_nseg = 0;
   const float half_main = (float)(std::max(h->cfg.resx, h->cfg.resy) / 2.0);
-  const int saveN = h->N; h->N = NB;     // loss partial count follows the pre-train batch
   size_t s = 0;
   for (int it = 0; it < pretrain_iters && rc == 0; ++it)
     for (int f = 0; f < F && rc == 0; ++f, ++s) {
@@ -647,24 +763,23 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       p.ys = d_ys ? d_ys + s * NB : nullptr; p.xs = d_xs ? d_xs + s * NB : nullptr;
       p.seed = seed; p.iter = (uint32_t)s; p.N = NB; p.resx = h->cfg.resx; p.resy = h->cfg.resy;
       p.half_main = half_main; p.t = (float)((double)f / (F / 2.0) - 1.0);
-      p.coords = h->coords; p.x0_tile = h->x0_tile;
+      p.coords = M.coords; p.x0_tile = M.x0_tile;
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
-      FwdArgs fa = fwd_args(h, M, h->coords, M.out_buf, NT, true);
-      if (af_launch_fwd(AF_NET_MAP1, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd"); break; }
-      PreLossArgs l{h->coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
+      if ((rc = launch_fwd(h, net, fwd_args(h, M, M.coords, M.out_buf, NT, true), true)) != 0) break;
+      PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      rc = step_tail(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * 8, false, NT, 0, 0);
+      if ((rc = launch_bwd(h, net, bwd_args(h, M, NT))) != 0) break;
+      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256);
     }
-  h->N = saveN;
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
   if (d_ys) { (void)hipFree(d_ys); (void)hipFree(d_xs); }
   if (rc) return rc;
   if (e != hipSuccess) return h->fail(AF_EHIP, "af_pretrain sync", e);
   if (losses_out) {
-    std::vector<float> tmp(steps * 8);
-    HCHK(hipMemcpy(tmp.data(), h->loss_log, steps * 32, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < steps; ++i) losses_out[i] = tmp[i * 8] / (float)NB;
+    std::vector<float> tmp(steps * AF_LOSS_W);
+    HCHK(hipMemcpy(tmp.data(), h->loss_log, steps * AF_LOSS_W * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < steps; ++i) losses_out[i] = tmp[i * AF_LOSS_W] / (float)NB;
   }
   std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
   return AF_OK;
@@ -677,7 +792,6 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
   if (n_iters == 0) return AF_OK;
   HCHK(hipSetDevice(h->device));
   const af_config& c = h->cfg;
-  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS];
   const int N = h->N;
   int rc = ensure_loss_log(h, n_iters); if (rc) return rc;
   int64_t* d_inds = nullptr;
@@ -686,52 +800,10 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
     HCHK(hipMemcpy(d_inds, inds, (size_t)n_iters * N * 8, hipMemcpyHostToDevice));
   }
   HCHK(hipMemsetAsync(h->counts, 0, 8, h->stream));
-  const int L = std::max(c.resx, c.resy);
-  const int NT_atlas = tiles_of(3 * N);
   for (int k = 0; k < n_iters && rc == 0; ++k) {
-    const int i = first_iter + k;
-    const bool glob = c.include_global_rigidity_loss && i <= c.stop_global_rigidity;
-    const int nseg = glob ? 9 : 7;
-    Sched& sc = h->sched[glob ? 0 : 1];
-    const int NT_map = tiles_of(nseg * N);
-    if (nseg != h->cur_nseg) {   // pad rows of the last tile must carry zero gradient
-      if (hipMemsetAsync(M.dout, 0, (size_t)M.nt_cap * 32 * 16, h->stream) != hipSuccess) { rc = h->fail(AF_EHIP, "memset dout"); break; }
-      h->cur_nseg = nseg;
-    }
-    {
-      Timer t(h, 0);
-      PrepArgs p{};
-      p.table = h->table; p.inds = d_inds ? d_inds + (size_t)k * N : nullptr; p.seed = seed; p.iter = (uint32_t)i;
-      p.N = N; p.resx = c.resx; p.resy = c.resy; p.F = c.number_of_frames;
-      p.half_main = (float)(L / 2.0); p.half_grad = (float)(c.resx / 2.0); p.half_frames = (float)(c.number_of_frames / 2.0);
-      p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
-      p.coords = h->coords; p.x0_tile = h->x0_tile; p.samples = h->samples; p.counts = h->counts;
-      if (af_launch_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "prep"); break; }
-    }
-    const bool split = h->overlap && NT_atlas < NT_map;
-    if (split && (rc = fork_streams(h)) != 0) break;
-    { Timer t(h, 1); FwdArgs fa = fwd_args(h, M, h->coords, M.out_buf, NT_map, true);
-      if (split) fa.NT = NT_atlas;
-      if (af_launch_fwd(AF_NET_MAP1, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd map"); break; } }
-    if (split) {
-      FwdArgs fb = fwd_args(h, M, h->coords, M.out_buf, NT_map, true); fb.tile0 = NT_atlas;
-      if (af_launch_fwd(AF_NET_MAP1, 1, &fb, h->stream2)) { rc = h->fail(AF_EHIP, "fwd map (stream 2)"); break; }
-    }
-    { Timer t(h, 2); FwdArgs fa = fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true);
-      if (af_launch_fwd(AF_NET_ATLAS, 1, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd atlas"); break; } }
-    if (split && (rc = join_streams(h)) != 0) break;
-    {
-      Timer t(h, 3);
-      LossArgs l{};
-      l.samples = h->samples; l.out_map = M.out_buf; l.out_atlas = A.out_buf; l.dout_map = M.dout; l.dout_atlas = A.dout;
-      l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
-      l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount; l.d_global = c.global_rigidity_derivative_amount_fg;
-      l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
-      l.c_grig = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_flow = c.optical_flow_coeff;
-      if (af_launch_loss_single(&l, h->stream)) { rc = h->fail(AF_EHIP, "loss"); break; }
-    }
-    h->adam_step += 1;
-    rc = step_tail(h, sc, h->adam_m, h->adam_v, h->adam_step, h->loss_log + (size_t)k * 8, true, NT_map, NT_atlas, 3 * N);
+    const int64_t* di = d_inds ? d_inds + (size_t)k * N : nullptr;
+    float* lo = h->loss_log + (size_t)k * AF_LOSS_W;
+    rc = h->seg ? enqueue_seg_step(h, first_iter + k, di, seed, lo) : enqueue_single_step(h, first_iter + k, di, seed, lo);
   }
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
@@ -740,42 +812,63 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
   if (e != hipSuccess) return h->fail(AF_EHIP, "af_train_steps sync", e);
   std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
   if (losses_out) {
-    std::vector<float> tmp((size_t)n_iters * 8);
-    HCHK(hipMemcpy(tmp.data(), h->loss_log, (size_t)n_iters * 32, hipMemcpyDeviceToHost));
+    std::vector<float> tmp((size_t)n_iters * AF_LOSS_W);
+    HCHK(hipMemcpy(tmp.data(), h->loss_log, (size_t)n_iters * AF_LOSS_W * 4, hipMemcpyDeviceToHost));
     bool nan = false;
+    const float invN = 1.f / (float)N;
     for (int k = 0; k < n_iters; ++k) {
       const int i = first_iter + k;
-      const bool glob = c.include_global_rigidity_loss && i <= c.stop_global_rigidity;
-      const float* s = &tmp[(size_t)k * 8]; float* o = losses_out + (size_t)k * 8;
-      const float invN = 1.f / (float)N;
-      o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = glob ? s[3] * invN : 0.f;
+      const bool glob = glob_on(c, i);
+      const float* s = &tmp[(size_t)k * AF_LOSS_W];
+      const float nf = s[AF_LOSS_W - 2], nb = s[AF_LOSS_W - 1];
+      float total;
       // mean over an empty set is NaN in the reference (loss_utils.py:317-320)
-      o[4] = 0.5f * (s[5] / s[7]) + 0.5f * (s[4] / s[6]);
-      o[5] = c.rigidity_coeff * o[2] + (glob ? c.global_rigidity_coeff_fg * o[3] : 0.f) + c.rgb_coeff * o[0] + c.optical_flow_coeff * o[4] + c.gradient_loss_coeff * o[1];
-      o[6] = s[6]; o[7] = s[7];
-      if (!(o[5] == o[5])) nan = true;
+      if (!h->seg) {
+        float* o = losses_out + (size_t)k * 8;
+        o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = glob ? s[3] * invN : 0.f;
+        o[4] = 0.5f * (s[5] / nb) + 0.5f * (s[4] / nf);
+        o[5] = c.rigidity_coeff * o[2] + (glob ? c.global_rigidity_coeff_fg * o[3] : 0.f) + c.rgb_coeff * o[0] + c.optical_flow_coeff * o[4] + c.gradient_loss_coeff * o[1];
+        o[6] = nf; o[7] = nb;
+        total = o[5];
+      } else {
+        float* o = losses_out + (size_t)k * 16;
+        const float boot = i > c.stop_bootstrapping_iteration ? 0.f : c.alpha_bootstrapping_factor;
+        o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = s[3] * invN;
+        o[4] = glob ? s[4] * invN : 0.f; o[5] = glob ? s[5] * invN : 0.f;
+        o[6] = 0.5f * (s[7] / nb) + 0.5f * (s[6] / nf);
+        o[7] = 0.5f * (s[9] / nb) + 0.5f * (s[8] / nf);
+        o[8] = (s[10] / nf + s[11] / nb) * 0.5f;
+        o[9] = s[12] * invN; o[10] = s[13] * invN;
+        o[11] = c.rigidity_coeff * (o[2] + o[3]) + c.rgb_coeff * o[0] + c.optical_flow_coeff * (o[6] + o[7]) + boot * o[9]
+              + c.alpha_flow_factor * o[8] + c.sparsity_coeff * o[10] + c.gradient_loss_coeff * o[1]
+              + (glob ? c.global_rigidity_coeff_fg * o[4] + c.global_rigidity_coeff_bg * o[5] : 0.f);
+        o[12] = nf; o[13] = nb; o[14] = 0.f; o[15] = 0.f;
+        total = o[11];
+      }
+      if (!(total == total)) nan = true;
     }
     if (nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss (a batch without valid flow pixels, as in the reference, or divergence)");
   }
   return AF_OK;
 }
 
-int af_step_work(const af_handle* h, int iter, int64_t* rows_map, int64_t* rows_atlas, double* flops) {
+int af_step_work(const af_handle* h, int iter, int64_t rows4[4], double* flops) {
   if (!h) return AF_EINVAL;
-  const bool glob = h->cfg.include_global_rigidity_loss && iter <= h->cfg.stop_global_rigidity;
-  const int64_t rm = (int64_t)(glob ? 9 : 7) * h->N, ra = (int64_t)3 * h->N;
-  if (rows_map) *rows_map = rm;
-  if (rows_atlas) *rows_atlas = ra;
-  if (flops) *flops = (double)rm * 1579008.0 + (double)ra * 2466784.0;   // BASELINE.md §3 per-row fwd+bwd FLOPs
+  const int64_t nseg = glob_on(h->cfg, iter) ? 9 : 7, N = h->N;
+  int64_t r[4] = {nseg * N, (h->seg ? 6 : 3) * N, h->seg ? nseg * N : 0, h->seg ? 5 * N : 0};
+  double f = 0;
+  for (int i = 0; i < 4; ++i) { if (rows4) rows4[i] = r[i]; f += (double)r[i] * kFlopRow[i]; }
+  if (flops) *flops = f;
   return AF_OK;
 }
 
 static int ensure_render(af_handle* h, int rows) {
   if (rows <= h->render_rows_cap) return 0;
-  (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
-  h->r_coords = h->r_uv = h->r_t = h->r_rgb = nullptr; h->r_sse = nullptr; h->render_rows_cap = 0;
+  (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al); (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
+  h->r_coords = h->r_uv = h->r_uv2 = h->r_al = h->r_t = h->r_rgb = nullptr; h->r_sse = nullptr; h->render_rows_cap = 0;
   const size_t rp = (size_t)tiles_of(rows) * 32;
-  HCHK(dalloc(&h->r_coords, rp * 4)); HCHK(dalloc(&h->r_uv, rp * 4)); HCHK(dalloc(&h->r_t, rp * 4));
+  HCHK(dalloc(&h->r_coords, rp * 4)); HCHK(dalloc(&h->r_uv, rp * 4)); HCHK(dalloc(&h->r_t, rp * 4 * (h->seg ? 2 : 1)));
+  if (h->seg) { HCHK(dalloc(&h->r_uv2, rp * 4)); HCHK(dalloc(&h->r_al, rp * 4)); }
   HCHK(dalloc(&h->r_rgb, rp * 3)); HCHK(dalloc(&h->r_sse, (rp + 255) / 256));
   h->render_rows_cap = rows;
   return 0;
@@ -810,9 +903,20 @@ int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out) {
   LCHK(af_launch_frame_coords(h->r_coords, h->cfg.resx, h->cfg.resy, half_main, t, NT * 32, h->stream));
   FwdArgs fm = fwd_args(h, h->nets[AF_NET_MAP1], h->r_coords, h->r_uv, NT, false);
   LCHK(af_launch_fwd(AF_NET_MAP1, 0, &fm, h->stream));
-  FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false);
-  LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
-  LCHK(af_launch_frame_finish(h->r_t, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
+  if (!h->seg) {
+    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false);
+    LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
+    LCHK(af_launch_frame_finish(h->r_t, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
+  } else {   // evaluate.py:302-337
+    FwdArgs f2 = fwd_args(h, h->nets[AF_NET_MAP2], h->r_coords, h->r_uv2, NT, false);
+    LCHK(af_launch_fwd(AF_NET_MAP2, 0, &f2, h->stream));
+    FwdArgs fl = fwd_args(h, h->nets[AF_NET_ALPHA], h->r_coords, h->r_al, NT, false);
+    LCHK(af_launch_fwd(AF_NET_ALPHA, 0, &fl, h->stream));
+    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, 2 * NT, false);
+    fa.in1 = h->r_uv2; fa.split_row = NT * 32;
+    LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
+    LCHK(af_launch_frame_finish_seg(h->r_t, h->r_al, (size_t)NT * 32, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
+  }
   const int nblk = (npix + 255) / 256;
   std::vector<double> part(nblk);
   HCHK(hipMemcpyAsync(part.data(), h->r_sse, (size_t)nblk * 8, hipMemcpyDeviceToHost, h->stream));

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
   float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
   {
-    const f32x4 v = *(const f32x4*)(a.in + (size_t)row * 4);
+    const f32x4 v = row < a.split_row ? *(const f32x4*)(a.in + (size_t)row * 4) : *(const f32x4*)(a.in1 + (size_t)(row - a.split_row) * 4);
     if constexpr (NS::IN == AF_IN_XYT) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) pe[p] = (h == 0 && p < 3) ? v[p] : 0.f;

@@ -187,7 +187,7 @@ def main():
 
 
     # ---- warm-up (W untimed steps, all kernel classes timed to find the dominant one)
-    af.set_timing(0xFF)
+    af.set_timing(0xFFFF)
     wfirst = max(0, first - W)
     if W > 0:
         af.train_steps(wfirst, W, None, seed=rank, return_losses=False)
@@ -203,7 +203,7 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic FLOPs per launch / mean HIP-event duration
     flops_launch = 0.0
     for k in range(K):
-        rm, ra, _ = af.step_work(first + k)
+        (rm, ra, _, _), _ = af.step_work(first + k)
         if dom in ("fwd_map", "bwd_map"):
             flops_launch += rm * FLOP_ROW[dom]
         elif dom in ("fwd_atlas", "bwd_atlas"):
@@ -213,7 +213,7 @@ def main():
     flops_launch /= K
     dom_ms = tk[dom][0] / max(tk[dom][1], 1)
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    total_flops = sum(af.step_work(first + k)[2] for k in range(K))
+    total_flops = sum(af.step_work(first + k)[1] for k in range(K))
 
     out = None
     if rank == 0:

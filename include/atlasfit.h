@@ -42,12 +42,23 @@ typedef struct af_config {
   float uv_mapping_scale;                        /* config :13 */
   float lr;                                      /* 1e-4, hard-coded at stage1_neural_atlas.py:134 */
   int32_t pretrain_batch;                        /* 10000, hard-coded at unwrap_utils.py:182-183 */
-  int32_t reserved[8];
+  /* ---- fg/bg dual-atlas path (src/stage1_neural_atlas_seg.py:27-107); read only when two_layer != 0 ---- */
+  int32_t two_layer;                             /* 0: stage1_neural_atlas.py   1: stage1_neural_atlas_seg.py */
+  int32_t number_of_channels_mapping2, number_of_layers_mapping2;   /* config :26-27  (256, 4) */
+  int32_t number_of_channels_alpha, number_of_layers_alpha;         /* config :21-22  (256, 8) */
+  int32_t positional_encoding_num_alpha;         /* config :18 (5) */
+  int32_t use_positional_encoding_mapping2;      /* config :34 (false; true is not built) */
+  int32_t global_rigidity_derivative_amount_bg;  /* config :41 */
+  int32_t stop_bootstrapping_iteration;          /* config :23 */
+  float global_rigidity_coeff_bg;                /* config :43 */
+  float alpha_bootstrapping_factor, alpha_flow_factor, sparsity_coeff;   /* config :16,17,30 */
+  int32_t reserved[4];
 } af_config;
 
 /* Replaces model construction + optimizer construction (stage1_neural_atlas.py:112-134).  Parameters
  * start at zero; load them with af_set_params. */
 int af_create(const af_config* cfg, int device_ordinal, af_handle** out);
+size_t af_config_size(void);                     /* sizeof(af_config) of this build: bindings check their mirror against it */
 void af_destroy(af_handle* h);
 const char* af_last_error(const af_handle* h);   /* h may be NULL: message of the last failed af_create */
 
@@ -74,12 +85,18 @@ int af_set_adam_state(af_handle* h, int net, const float* exp_avg, const float* 
 int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, const int64_t* xs,
                 uint64_t seed, float* losses_out);
 
-/* The loop body (src/stage1_neural_atlas.py:151-231) for iterations first_iter .. first_iter+n_iters-1.
+/* The loop body (src/stage1_neural_atlas.py:151-231, or src/stage1_neural_atlas_seg.py:191-315 for a
+ * two_layer handle) for iterations first_iter .. first_iter+n_iters-1.
  * inds: [n_iters][samples_batch] values of inds_foreground (:159-160), or NULL for the device sampler.
- * losses_out: [n_iters][8] = rgb, gradient, rigidity, global rigidity, flow, total, #valid fwd, #valid bwd
- * (the un-weighted terms of :186-218 and the weighted sum of :220-227), or NULL. */
+ * losses_out: [n_iters][af_loss_width(h)] or NULL.
+ *   single (width 8): rgb, gradient, rigidity, global rigidity, flow, total, #valid fwd, #valid bwd
+ *     (the un-weighted terms of :186-218 and the weighted sum of :220-227);
+ *   two_layer (width 16): rgb, gradient, rigidity1, rigidity2, global rigidity1, global rigidity2, flow1, flow2,
+ *     alpha-flow, alpha bootstrapping (BCE), sparsity, total, #valid fwd, #valid bwd, 0, 0
+ *     (stage1_neural_atlas_seg.py:237-311). */
 int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* inds, uint64_t seed,
                    float* losses_out);
+int af_loss_width(const af_handle* h);
 
 /* Forward-only reconstruction of one frame (src/models/stage_1/evaluate.py:640-661):
  * rgb_out (resy,resx,3) host buffer or NULL; sse_out: sum of squared error vs the input frame (fp64). */
@@ -96,11 +113,13 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);
 /* Time the most recent kernels: returns accumulated HIP-event milliseconds per kernel class since the last
- * reset: [0]=prep [1]=fwd_map [2]=fwd_atlas [3]=loss [4]=bwd_atlas [5]=bwd_map [6]=dw [7]=adam; counts[8]. */
+ * reset: [0]=prep [1]=fwd_map1 [2]=fwd_atlas [3]=loss [4]=bwd_atlas [5]=bwd_map1 [6]=dw [7]=adam
+ * [8]=fwd_map2 [9]=fwd_alpha [10]=bwd_map2 [11]=bwd_alpha; ms16[16], counts16[16]. */
 int af_set_timing(af_handle* h, int class_mask);   /* bit i enables HIP-event timing of kernel class i */
-int af_get_timing(af_handle* h, double* ms8, int64_t* counts8, int reset);
-/* Algorithmic work of ONE train step at the given iteration (rows per net, FLOPs): see DESIGN.md. */
-int af_step_work(const af_handle* h, int iter, int64_t* rows_map, int64_t* rows_atlas, double* flops);
+int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, int reset);
+/* Algorithmic work of ONE train step at the given iteration: MLP rows per net (indexed by af_net) and the
+ * fwd+bwd FLOPs of the step. */
+int af_step_work(const af_handle* h, int iter, int64_t rows4[4], double* flops);
 
 #ifdef __cplusplus
 }

@@ -346,3 +346,187 @@ def flat_params(model):
 
 def flat_grads(model):
     return torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()]).numpy().copy()
+
+
+# ================================================================================================
+# fg/bg dual-atlas path with the alpha MLP — src/stage1_neural_atlas_seg.py (BASELINE configs[4])
+def build_seg_models(config, seed=None):
+    """stage1_neural_atlas_seg.py:127-161 — construction (= RNG consumption) order mapping1, mapping2, atlas, alpha."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    m1 = OracleIMLP(3, 2, config["number_of_channels_mapping1"], config["use_positional_encoding_mapping1"],
+                    config["number_of_positional_encoding_mapping1"], [], config["number_of_layers_mapping1"])
+    m2 = OracleIMLP(3, 2, config["number_of_channels_mapping2"], config["use_positional_encoding_mapping2"],
+                    config["number_of_positional_encoding_mapping2"], [], config["number_of_layers_mapping2"])
+    atlas = OracleIMLP(2, 3, config["number_of_channels_atlas"], True, config["positional_encoding_num_atlas"],
+                       [4, 7], config["number_of_layers_atlas"])
+    alpha = OracleIMLP(3, 1, config["number_of_channels_alpha"], True, config["positional_encoding_num_alpha"],
+                       [], config["number_of_layers_alpha"])
+    return m1, m2, atlas, alpha
+
+
+def alpha_of(model_alpha, xyt):
+    """stage1_neural_atlas_seg.py:224-227: tanh output -> (0.001, 0.991)."""
+    a = 0.5 * (model_alpha(xyt) + 1.0)
+    a = a * 0.99
+    return a + 0.001
+
+
+def gradient_loss_seg(dx, dy, jif, m1, m2, atlas, rgb_out, resx, nframes, model_alpha):
+    """loss_utils.py:173-224 (alpha is re-evaluated at the +1 neighbours; everything normalised by resx/2)."""
+    t = jif[2] / (nframes / 2.0) - 1
+    xp1 = torch.cat(((jif[0] + 1) / (resx / 2) - 1, jif[1] / (resx / 2) - 1, t), dim=1)
+    yp1 = torch.cat((jif[0] / (resx / 2) - 1, (jif[1] + 1) / (resx / 2) - 1, t), dim=1)
+    ax = alpha_of(model_alpha, xp1)
+    ay = alpha_of(model_alpha, yp1)
+    dx_gt = dx[jif[1], jif[0], :, jif[2]].squeeze(1)
+    dy_gt = dy[jif[1], jif[0], :, jif[2]].squeeze(1)
+    uv2_y = m2(yp1); uv2_x = m2(xp1); uv1_y = m1(yp1); uv1_x = m1(xp1)
+    r1y = (atlas(uv1_y * 0.5 + 0.5) + 1.0) * 0.5
+    r1x = (atlas(uv1_x * 0.5 + 0.5) + 1.0) * 0.5
+    r2y = (atlas(uv2_y * 0.5 - 0.5) + 1.0) * 0.5
+    r2x = (atlas(uv2_x * 0.5 - 0.5) + 1.0) * 0.5
+    ry = r1y * ay + r2y * (1.0 - ay)
+    rx = r1x * ax + r2x * (1.0 - ax)
+    return torch.mean((dx_gt - (rx - rgb_out)).norm(dim=1) ** 2 + (dy_gt - (ry - rgb_out)).norm(dim=1) ** 2)
+
+
+def optical_flow_alpha_loss(model_alpha, jif, alpha, flows_rev, mask_rev, larger_dim, nframes, flows, mask):
+    """loss_utils.py:385-408 (Eq. 12): L1 between alpha at a pixel and alpha at its flow match."""
+    _, xyt_f, rows_f = flow_matches(jif, mask, flows, larger_dim, nframes, True, alpha)
+    a_f = alpha_of(model_alpha, xyt_f)
+    l_next = (alpha[rows_f] - a_f).abs().mean()
+    _, xyt_b, rows_b = flow_matches(jif, mask_rev, flows_rev, larger_dim, nframes, False, alpha)
+    a_b = alpha_of(model_alpha, xyt_b)
+    l_prev = (a_b - alpha[rows_b]).abs().mean()
+    return (l_next + l_prev) * 0.5
+
+
+SEG_TERMS = ("rgb", "gradient", "rigidity1", "rigidity2", "global_rigidity1", "global_rigidity2", "flow1", "flow2",
+             "flow_alpha", "alpha_bootstrapping", "sparsity", "total")
+
+
+class SegVideo(Video):
+    """load_input_data outputs (unwrap_utils.py:40-103): Video + mask_frames (resy, resx, F), fractional fg mask."""
+
+    def __init__(self, frames, flows, flows_rev, mask, mask_rev, mask_frames):
+        super().__init__(frames, flows, flows_rev, mask, mask_rev)
+        self.mask_frames = mask_frames
+
+
+def seg_loop_body(i, jif, video, m1, m2, atlas, model_alpha, config):
+    """stage1_neural_atlas_seg.py:193-311: all loss terms and the weighted total for one batch."""
+    c = config
+    nf, L = video.F, video.larger_dim
+    boot = 0 if i > c["stop_bootstrapping_iteration"] else c["alpha_bootstrapping_factor"]
+    rgb_gt = video.video_frames[jif[1], jif[0], :, jif[2]].squeeze(1)
+    a_gt = video.mask_frames[jif[1], jif[0], jif[2]].squeeze(1).unsqueeze(-1)
+    xyt = torch.cat((jif[0] / (L / 2) - 1, jif[1] / (L / 2) - 1, jif[2] / (nf / 2.0) - 1), dim=1)
+    uv1 = m1(xyt)
+    uv2 = m2(xyt)
+    alpha = alpha_of(model_alpha, xyt)
+    rgb1 = (atlas(uv1 * 0.5 + 0.5) + 1.0) * 0.5
+    rgb2 = (atlas(uv2 * 0.5 - 0.5) + 1.0) * 0.5
+    rgb = rgb1 * alpha + rgb2 * (1.0 - alpha)
+    grad_l = gradient_loss_seg(video.video_frames_dx, video.video_frames_dy, jif, m1, m2, atlas, rgb, video.resx, nf, model_alpha)
+    rgb_l = (torch.norm(rgb - rgb_gt, dim=1) ** 2).mean()
+    sparse_l = (torch.norm(rgb1 * (1.0 - alpha), dim=1) ** 2).mean()
+    s = c["uv_mapping_scale"]
+    rig1 = rigidity_loss(jif, c["derivative_amount"], L, nf, m1, uv1, s)
+    rig2 = rigidity_loss(jif, c["derivative_amount"], L, nf, m2, uv2, s)
+    glob = c["include_global_rigidity_loss"] and i <= c["stop_global_rigidity"]
+    zero = torch.zeros(())
+    grig1 = rigidity_loss(jif, c["global_rigidity_derivative_amount_fg"], L, nf, m1, uv1, s) if glob else zero
+    grig2 = rigidity_loss(jif, c["global_rigidity_derivative_amount_bg"], L, nf, m2, uv2, s) if glob else zero
+    fl1 = optical_flow_loss(jif, uv1, video.optical_flows_reverse, video.optical_flows_reverse_mask, L, nf, m1,
+                            video.optical_flows, video.optical_flows_mask, s, alpha)
+    fl2 = optical_flow_loss(jif, uv2, video.optical_flows_reverse, video.optical_flows_reverse_mask, L, nf, m2,
+                            video.optical_flows, video.optical_flows_mask, s, 1 - alpha)
+    fla = optical_flow_alpha_loss(model_alpha, jif, alpha, video.optical_flows_reverse, video.optical_flows_reverse_mask,
+                                  L, nf, video.optical_flows, video.optical_flows_mask)
+    bce = torch.mean(-a_gt * torch.log(alpha) - (1 - a_gt) * torch.log(1 - alpha))
+    total = (c["rigidity_coeff"] * (rig1 + rig2) + rgb_l * c["rgb_coeff"] + c["optical_flow_coeff"] * (fl1 + fl2)
+             + bce * boot + fla * c["alpha_flow_factor"] + sparse_l * c["sparsity_coeff"] + grad_l * c["gradient_loss_coeff"])
+    if glob:
+        total = total + c["global_rigidity_coeff_fg"] * grig1 + c["global_rigidity_coeff_bg"] * grig2
+    vals = (rgb_l, grad_l, rig1, rig2, grig1, grig2, fl1, fl2, fla, bce, sparse_l, total)
+    return total, dict(zip(SEG_TERMS, vals))
+
+
+class SegAtlasTrainer:
+    """Optimisation state of stage1_neural_atlas_seg.main(): four nets + Adam(lr 1e-4), param-group order
+    mapping1, mapping2, alpha, atlas (:165-169)."""
+
+    def __init__(self, config, video, seed=None, models=None):
+        self.config, self.video = config, video
+        self.m1, self.m2, self.atlas, self.alpha = models if models is not None else build_seg_models(config, seed)
+        self.opt = torch.optim.Adam([{"params": list(self.m1.parameters())}, {"params": list(self.m2.parameters())},
+                                     {"params": list(self.alpha.parameters())}, {"params": list(self.atlas.parameters())}], lr=1e-4)
+        self.jif_all = get_tuples(video.F, video.resy, video.resx)
+
+    def _loss(self, i, inds):
+        jif = self.jif_all[:, inds.view(-1, 1)]
+        return seg_loop_body(i, jif, self.video, self.m1, self.m2, self.atlas, self.alpha, self.config)
+
+    def step(self, i, inds):
+        total, terms = self._loss(i, inds)
+        self.opt.zero_grad()
+        total.backward()
+        self.opt.step()
+        return {k: float(v.detach()) for k, v in terms.items()}
+
+    def loss_and_grads(self, i, inds):
+        total, terms = self._loss(i, inds)
+        self.opt.zero_grad()
+        total.backward()
+        return {k: float(v.detach()) for k, v in terms.items()}
+
+
+def render_frame_seg(m1, m2, atlas, model_alpha, resx, resy, nframes, f, chunk=100000):
+    """evaluate.py:302-337: rgb = rgb1*alpha + rgb2*(1-alpha) for every pixel of frame f."""
+    larger_dim = np.maximum(np.int64(resx), np.int64(resy))
+    ys, xs = torch.where(torch.ones(resy, resx) > 0)
+    out = torch.zeros(resy, resx, 3)
+    with torch.no_grad():
+        n = int(np.ceil(ys.shape[0] / chunk))
+        for yc, xc in zip(np.array_split(ys.numpy(), n), np.array_split(xs.numpy(), n)):
+            yy = torch.from_numpy(yc).unsqueeze(1) / (larger_dim / 2) - 1
+            xx = torch.from_numpy(xc).unsqueeze(1) / (larger_dim / 2) - 1
+            xyt = torch.cat((xx, yy, (f / (nframes / 2.0) - 1) * torch.ones_like(yy)), dim=1)
+            r1 = (atlas(m1(xyt) * 0.5 + 0.5) + 1) * 0.5
+            r2 = (atlas(m2(xyt) * 0.5 - 0.5) + 1) * 0.5
+            a = alpha_of(model_alpha, xyt)
+            out[yc, xc] = r1 * a + r2 * (1.0 - a)
+    return out
+
+
+def mean_psnr_seg(m1, m2, atlas, model_alpha, video):
+    vals = []
+    for f in range(video.F):
+        rec = render_frame_seg(m1, m2, atlas, model_alpha, video.resx, video.resy, video.F, f)
+        vals.append(psnr(video.video_frames[:, :, :, f].numpy(), rec.numpy()))
+    return float(np.mean(vals)), vals
+
+
+def synthetic_seg_video(resx, resy, nframes, seed=0):
+    """synthetic_video + a soft-edged disc moving across the frame as foreground mask (fractional values,
+    like the bilinearly-resized masks the reference actually feeds, unwrap_utils.py:68-70) with its own colour
+    texture composited over the background."""
+    v = synthetic_video(resx, resy, nframes, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    yy, xx = np.mgrid[0:resy, 0:resx].astype(np.float64)
+    r = 0.22 * min(resx, resy)
+    cx0, cy0 = rng.uniform(0.3, 0.4) * resx, rng.uniform(0.4, 0.6) * resy
+    col = rng.uniform(0.2, 0.9, 3)
+    masks = np.zeros((resy, resx, nframes), np.float32)
+    frames = v.video_frames.numpy().copy()
+    for f in range(nframes):
+        cx, cy = cx0 + 0.8 * f, cy0 - 0.3 * f
+        d = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+        m = np.clip((r - d) / 2.0 + 0.5, 0.0, 1.0)
+        tex = 0.5 + 0.5 * np.sin(0.9 * (xx - cx))[..., None] * np.cos(0.7 * (yy - cy))[..., None] * col
+        frames[:, :, :, f] = (m[..., None] * tex + (1 - m[..., None]) * frames[:, :, :, f]).astype(np.float32)
+        masks[:, :, f] = m
+    t = torch.from_numpy
+    return SegVideo(t(frames), v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask,
+                    v.optical_flows_reverse_mask, t(masks))

@@ -1,0 +1,162 @@
+"""Generate tests/golden/seg_small.npz for the fg/bg dual-atlas path (src/stage1_neural_atlas_seg.py) by
+running the REFERENCE's own modules (read-only import from /root/reference) on seeded synthetic inputs, and
+check the oracle restatement (oracle/atlas_oracle.py, seg section) against them while doing so.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_seg.py        (build container only)
+
+The trajectory starts from the seeded torch initialisation (RNG-only, hence reproducible anywhere with the
+same torch build), so no start-state blob is needed; the pre-trained regime is covered on the GPU by
+oracle-vs-HIP comparisons that need no fixture.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("AF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+for _name in ("cv2", "imageio"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+
+from src.models.stage_1.implicit_neural_networks import IMLP                                    # noqa: E402
+from src.models.stage_1.loss_utils import (get_gradient_loss, get_rigidity_loss, get_optical_flow_loss,   # noqa: E402
+                                           get_optical_flow_alpha_loss)
+from src.models.stage_1.unwrap_utils import get_tuples                                           # noqa: E402
+
+from oracle import atlas_oracle as O                                                             # noqa: E402
+
+CONFIG = {
+    "samples_batch": 256, "optical_flow_coeff": 500.0, "derivative_amount": 1, "rgb_coeff": 5000,
+    "rigidity_coeff": 1.0, "uv_mapping_scale": 0.8, "alpha_bootstrapping_factor": 2000.0, "alpha_flow_factor": 4900.0,
+    "positional_encoding_num_alpha": 5, "number_of_channels_atlas": 256, "number_of_layers_atlas": 8,
+    "number_of_channels_alpha": 256, "number_of_layers_alpha": 8, "stop_bootstrapping_iteration": 7,
+    "number_of_channels_mapping1": 256, "number_of_layers_mapping1": 6, "number_of_channels_mapping2": 256,
+    "number_of_layers_mapping2": 4, "gradient_loss_coeff": 1000, "use_gradient_loss": True, "sparsity_coeff": 1000.0,
+    "positional_encoding_num_atlas": 10, "use_positional_encoding_mapping1": False,
+    "number_of_positional_encoding_mapping1": 4, "use_positional_encoding_mapping2": False,
+    "number_of_positional_encoding_mapping2": 2, "include_global_rigidity_loss": True,
+    "global_rigidity_derivative_amount_fg": 100, "global_rigidity_derivative_amount_bg": 50,
+    "global_rigidity_coeff_fg": 5.0, "global_rigidity_coeff_bg": 50.0, "stop_global_rigidity": 5,
+}
+RESX, RESY, NF, VSEED, WSEED = 40, 24, 6, 5, 4321
+K_ITERS = 10     # global rigidity switches off after iteration 5, alpha bootstrapping after iteration 7
+
+
+def ref_models(seed):
+    """stage1_neural_atlas_seg.py:127-161."""
+    torch.manual_seed(seed)
+    c = CONFIG
+    m1 = IMLP(input_dim=3, output_dim=2, hidden_dim=256, use_positional=False, positional_dim=4, num_layers=6, skip_layers=[], verbose=False)
+    m2 = IMLP(input_dim=3, output_dim=2, hidden_dim=256, use_positional=False, positional_dim=2, num_layers=4, skip_layers=[], verbose=False)
+    at = IMLP(input_dim=2, output_dim=3, hidden_dim=256, use_positional=True, positional_dim=10, num_layers=8, skip_layers=[4, 7], verbose=False)
+    al = IMLP(input_dim=3, output_dim=1, hidden_dim=256, use_positional=True, positional_dim=c["positional_encoding_num_alpha"], num_layers=8, skip_layers=[], verbose=False)
+    return m1, m2, at, al
+
+
+def ref_seg_iteration(i, jif_current, v, m1, m2, atlas, model_alpha, c, device="cpu"):
+    """Loop body of src/stage1_neural_atlas_seg.py:193-311 driven with the reference's own loss functions."""
+    nf, L = v.F, v.larger_dim
+    boot = 0 if i > c["stop_bootstrapping_iteration"] else c["alpha_bootstrapping_factor"]
+    gfg = 0 if i > c["stop_global_rigidity"] else c["global_rigidity_coeff_fg"]
+    gbg = 0 if i > c["stop_global_rigidity"] else c["global_rigidity_coeff_bg"]
+    rgb_current = v.video_frames[jif_current[1, :], jif_current[0, :], :, jif_current[2, :]].squeeze(1)
+    alpha_maskrcnn = v.mask_frames[jif_current[1, :], jif_current[0, :], jif_current[2, :]].squeeze(1).unsqueeze(-1)
+    xyt = torch.cat((jif_current[0, :] / (L / 2) - 1, jif_current[1, :] / (L / 2) - 1, jif_current[2, :] / (nf / 2.0) - 1), dim=1)
+    uv1 = m1(xyt); uv2 = m2(xyt)
+    alpha = 0.5 * (model_alpha(xyt) + 1.0); alpha = alpha * 0.99; alpha = alpha + 0.001
+    rgb1 = (atlas(uv1 * 0.5 + 0.5) + 1.0) * 0.5
+    rgb2 = (atlas(uv2 * 0.5 - 0.5) + 1.0) * 0.5
+    rgb = rgb1 * alpha + rgb2 * (1.0 - alpha)
+    grad = get_gradient_loss(v.video_frames_dx, v.video_frames_dy, jif_current, m1, m2, atlas, rgb, device, v.resx, nf, model_alpha)
+    rgb_not = rgb1 * (1.0 - alpha)
+    rgb_l = (torch.norm(rgb - rgb_current, dim=1) ** 2).mean()
+    sparse = (torch.norm(rgb_not, dim=1) ** 2).mean()
+    s = c["uv_mapping_scale"]
+    rig1 = get_rigidity_loss(jif_current, c["derivative_amount"], L, nf, m1, uv1, device, uv_mapping_scale=s)
+    rig2 = get_rigidity_loss(jif_current, c["derivative_amount"], L, nf, m2, uv2, device, uv_mapping_scale=s)
+    glob = c["include_global_rigidity_loss"] and i <= c["stop_global_rigidity"]
+    if glob:
+        grig1 = get_rigidity_loss(jif_current, c["global_rigidity_derivative_amount_fg"], L, nf, m1, uv1, device, uv_mapping_scale=s)
+        grig2 = get_rigidity_loss(jif_current, c["global_rigidity_derivative_amount_bg"], L, nf, m2, uv2, device, uv_mapping_scale=s)
+    fl1 = get_optical_flow_loss(jif_current, uv1, v.optical_flows_reverse, v.optical_flows_reverse_mask, L, nf, m1,
+                                v.optical_flows, v.optical_flows_mask, s, device, use_alpha=True, alpha=alpha)
+    fl2 = get_optical_flow_loss(jif_current, uv2, v.optical_flows_reverse, v.optical_flows_reverse_mask, L, nf, m2,
+                                v.optical_flows, v.optical_flows_mask, s, device, use_alpha=True, alpha=1 - alpha)
+    fla = get_optical_flow_alpha_loss(model_alpha, jif_current, alpha, v.optical_flows_reverse, v.optical_flows_reverse_mask, L, nf,
+                                      v.optical_flows, v.optical_flows_mask, device)
+    bce = torch.mean(-alpha_maskrcnn * torch.log(alpha) - (1 - alpha_maskrcnn) * torch.log(1 - alpha))
+    if glob:
+        loss = c["rigidity_coeff"] * (rig1 + rig2) + gfg * grig1 + gbg * grig2 + rgb_l * c["rgb_coeff"] + c["optical_flow_coeff"] * (fl1 + fl2) \
+            + bce * boot + fla * c["alpha_flow_factor"] + sparse * c["sparsity_coeff"] + grad * c["gradient_loss_coeff"]
+    else:
+        loss = c["rigidity_coeff"] * (rig1 + rig2) + rgb_l * c["rgb_coeff"] + c["optical_flow_coeff"] * (fl1 + fl2) \
+            + bce * boot + fla * c["alpha_flow_factor"] + sparse * c["sparsity_coeff"] + grad * c["gradient_loss_coeff"]
+    terms = [rgb_l, grad, rig1, rig2, grig1 if glob else 0.0, grig2 if glob else 0.0, fl1, fl2, fla, bce, sparse, loss]
+    return loss, [float(t) for t in terms]
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    c = CONFIG
+    N = c["samples_batch"]
+    video = O.synthetic_seg_video(RESX, RESY, NF, seed=VSEED)
+
+    # ---- networks: reference init == oracle init, forward parity (mapping2 and alpha are new here)
+    rm = ref_models(WSEED)
+    om = O.build_seg_models(c, seed=WSEED)
+    for r, o in zip(rm, om):
+        for (kn, pr), (_, po) in zip(r.state_dict().items(), o.state_dict().items()):
+            assert torch.equal(pr, po), kn
+    g = torch.Generator().manual_seed(11)
+    rows_xyt = torch.rand(96, 3, generator=g) * 2 - 1
+    with torch.no_grad():
+        fwd_map2 = rm[1](rows_xyt); fwd_alpha = rm[3](rows_xyt)
+        assert torch.equal(fwd_map2, om[1](rows_xyt)) and torch.equal(fwd_alpha, om[3](rows_xyt))
+
+    jif_all = get_tuples(NF, video.video_frames)
+    opt = torch.optim.Adam([{"params": list(rm[0].parameters())}, {"params": list(rm[1].parameters())},
+                            {"params": list(rm[3].parameters())}, {"params": list(rm[2].parameters())}], lr=0.0001)
+    tr = O.SegAtlasTrainer(c, video, models=om)
+    torch.manual_seed(WSEED + 3)
+    inds = torch.stack([torch.randint(jif_all.shape[1], (N, 1)).view(-1) for _ in range(K_ITERS)])
+    init_sums = [float(np.abs(O.flat_params(m)).sum()) for m in rm]
+    losses, grads0 = [], None
+    for i in range(K_ITERS):
+        jif_current = jif_all[:, inds[i].view(-1, 1)]
+        loss, terms = ref_seg_iteration(i, jif_current, video, *rm, c)
+        opt.zero_grad(); loss.backward()
+        if i == 0:
+            grads0 = [O.flat_grads(m) for m in rm]
+        opt.step()
+        o_terms = tr.step(i, inds[i])
+        ref_t = np.array(terms); ora_t = np.array([o_terms[k] for k in O.SEG_TERMS])
+        assert np.allclose(ref_t, ora_t, rtol=2e-5, atol=1e-7), (i, ref_t, ora_t)
+        losses.append(terms)
+    ends = [O.flat_params(m) for m in rm]
+    for e, m in zip(ends, om):
+        assert np.allclose(e, O.flat_params(m), atol=2e-6)
+    ref_psnr, _ = O.mean_psnr_seg(*rm, video)
+    if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
+        print("seg restatement == reference modules (check only, fixtures untouched)")
+        return
+    np.savez_compressed(
+        os.path.join(out_dir, "seg_small.npz"),
+        resx=RESX, resy=RESY, nframes=NF, video_seed=VSEED, weight_seed=WSEED, samples_batch=N,
+        config_keys=np.array(sorted(c.keys())), config_vals=np.array([float(c[k]) for k in sorted(c.keys())]),
+        rows_xyt=rows_xyt.numpy(), fwd_map2=fwd_map2.numpy(), fwd_alpha=fwd_alpha.numpy(),
+        init_checksum=np.array(init_sums), inds=inds.numpy().astype(np.int32), losses=np.array(losses, np.float64),
+        grads0_samples=np.concatenate([g_[::97] for g_ in grads0]), grads0_norms=np.array([float(np.linalg.norm(g_)) for g_ in grads0]),
+        end_samples=np.concatenate([e[::97] for e in ends]), psnr=ref_psnr,
+        video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.mask_frames.double().sum()),
+    )
+    print("seg golden written; losses[0] =", losses[0], "psnr =", ref_psnr)
+
+
+if __name__ == "__main__":
+    main()

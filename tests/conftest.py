@@ -46,6 +46,36 @@ def golden():
     return g
 
 
+def _typed_config(keys, vals):
+    cfg = {}
+    for k, v in zip(keys, vals):
+        k = str(k); v = float(v)
+        if k.startswith(("use_", "include_")):
+            cfg[k] = bool(v)
+        elif k.startswith(("number_of_", "positional_encoding_num", "stop_", "global_rigidity_derivative_amount")) or k in ("samples_batch", "derivative_amount"):
+            cfg[k] = int(v)
+        else:
+            cfg[k] = v
+    return cfg
+
+
+@pytest.fixture(scope="session")
+def golden_seg():
+    """Fixture of the fg/bg dual-atlas path, produced from the reference's modules by oracle/make_golden_seg.py."""
+    g = dict(np.load(os.path.join(GOLDEN, "seg_small.npz"), allow_pickle=False))
+    g["config"] = _typed_config(g["config_keys"], g["config_vals"])
+    return g
+
+
+@pytest.fixture(scope="session")
+def small_seg_video(golden_seg):
+    from oracle import atlas_oracle as O
+    v = O.synthetic_seg_video(int(golden_seg["resx"]), int(golden_seg["resy"]), int(golden_seg["nframes"]), seed=int(golden_seg["video_seed"]))
+    assert abs(float(v.video_frames.double().sum()) - float(golden_seg["video_checksum"])) < 1e-6
+    assert abs(float(v.mask_frames.double().sum()) - float(golden_seg["mask_checksum"])) < 1e-6
+    return v
+
+
 @pytest.fixture(scope="session")
 def small_video(golden):
     from oracle import atlas_oracle as O

@@ -26,11 +26,14 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(lib, s), s
 
 
-def test_config_struct_layout():
+def test_config_struct_layout(lib):
     import ctypes
     import aiod_amd
     c = aiod_amd.default_config(768, 432, 80)
-    assert ctypes.sizeof(aiod_amd.AfConfig) == 4 * (15 + 7 + 1 + 8)
+    assert ctypes.sizeof(aiod_amd.AfConfig) == 4 * (15 + 7 + 1 + 9 + 4 + 4) == lib.af_config_size()
+    c2 = aiod_amd.default_config(768, 432, 80, two_layer=True)
+    assert c.two_layer == 0 and c2.two_layer == 1 and c2.number_of_layers_mapping2 == 4 and c2.positional_encoding_num_alpha == 5
+    assert abs(c2.alpha_flow_factor - 4900.0) < 1e-3 and c2.stop_bootstrapping_iteration == 10000
     assert c.samples_batch == 10000 and c.stop_global_rigidity == 5000 and abs(c.uv_mapping_scale - 0.8) < 1e-7
 
 

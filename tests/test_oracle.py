@@ -79,3 +79,38 @@ def test_restatement_against_live_reference_modules():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", AF_GOLDEN_CHECK_ONLY="1")
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+# ---- fg/bg dual-atlas path (src/stage1_neural_atlas_seg.py)
+def test_seg_init_and_forward_match_reference_fixture(golden_seg):
+    ms = O.build_seg_models(golden_seg["config"], seed=int(golden_seg["weight_seed"]))
+    for m, ref in zip(ms, golden_seg["init_checksum"]):
+        assert abs(float(np.abs(O.flat_params(m)).sum()) - float(ref)) < 1e-3
+    rows = torch.from_numpy(golden_seg["rows_xyt"])
+    with torch.no_grad():
+        assert np.abs(ms[1](rows).numpy() - golden_seg["fwd_map2"]).max() < 1e-6
+        assert np.abs(ms[3](rows).numpy() - golden_seg["fwd_alpha"]).max() < 1e-6
+
+
+def test_alpha_pe_layout():
+    """in_dim 3: feature index = 6k + [sin x0,x1,x2, cos x0,x1,x2] (implicit_neural_networks.py:9-13)."""
+    x = torch.tensor([[0.25, -0.5, 0.125]])
+    b = torch.tensor([(2 ** j) * np.pi for j in range(2)])
+    pe = O.positional_encoding(x, b)[0].numpy()
+    exp = []
+    for k in range(2):
+        exp += [np.sin(v * float(b[k])) for v in (0.25, -0.5, 0.125)] + [np.cos(v * float(b[k])) for v in (0.25, -0.5, 0.125)]
+    assert np.allclose(pe, np.array(exp, np.float32), atol=1e-6)
+
+
+def test_seg_trajectory_matches_reference_fixture(golden_seg, small_seg_video):
+    tr = O.SegAtlasTrainer(golden_seg["config"], small_seg_video, seed=int(golden_seg["weight_seed"]))
+    inds = torch.from_numpy(golden_seg["inds"].astype(np.int64))
+    for i in range(inds.shape[0]):
+        t = tr.step(i, inds[i])
+        got = np.array([t[k] for k in O.SEG_TERMS])
+        assert np.allclose(got, golden_seg["losses"][i], rtol=2e-4, atol=1e-7), (i, got, golden_seg["losses"][i])
+    ends = np.concatenate([O.flat_params(m)[::97] for m in (tr.m1, tr.m2, tr.atlas, tr.alpha)])
+    assert np.abs(ends - golden_seg["end_samples"]).max() < 1e-5
+    mean, _ = O.mean_psnr_seg(tr.m1, tr.m2, tr.atlas, tr.alpha, small_seg_video)
+    assert abs(mean - float(golden_seg["psnr"])) < 1e-3
