@@ -104,6 +104,14 @@ typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
 AF_DEV __amdgpu_buffer_rsrc_t af_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
+// Same, for a wave-uniform base the compiler cannot prove uniform (e.g. carried around a loop): pin the
+// descriptor words to SGPRs.  A descriptor left in VGPRs turns EVERY buffer access into a waterfall loop
+// (4 v_readfirstlane + compare + saveexec + branch per instruction).
+AF_DEV __amdgpu_buffer_rsrc_t af_rsrc_uniform(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 AF_DEV float af_bl32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }

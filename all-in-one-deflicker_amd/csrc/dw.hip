@@ -96,7 +96,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
   constexpr int pld = TI * 32;
-  const auto rblk = af_rsrc(blk, jb.part_blk * 4);
+  const auto rblk = af_rsrc_uniform(blk, jb.part_blk * 4);
   if (store_w) {
     const int voff = ((a0 * 32 + 4 * h) * pld + b0 * 32 + m) * 4;
 #pragma unroll

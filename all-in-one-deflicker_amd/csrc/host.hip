@@ -20,6 +20,7 @@ extern "C" {
 int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s);
 int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s);
 int af_mlp_init();
+int af_mlp_chunk_bytes(int net, int which);
 int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s);
 int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
@@ -169,6 +170,25 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
     else for (int c = 0; c < 4; ++c) { n.bchunks.push_back({(uint32_t)boff, (uint32_t)(8 * gbytes)}); boff += 8 * gbytes; }
   }
   b_cursor += boff / 4;
+}
+
+// The kernels walk the weight stream with compile-time chunk sizes (mlp.hip ChunkBytes): the planned layout must
+// be exactly that sequence, contiguous.
+bool check_chunk_plan(const NetDesc& n) {
+  std::vector<int> f, b;
+  f.push_back(af_mlp_chunk_bytes(n.id, 0));
+  for (int l = 1; l < n.NL - 1; ++l) { for (int c = 0; c < 4; ++c) f.push_back(af_mlp_chunk_bytes(n.id, 1)); if ((n.skip >> l) & 1) f.push_back(af_mlp_chunk_bytes(n.id, 2)); }
+  f.push_back(af_mlp_chunk_bytes(n.id, 3));
+  b.push_back(af_mlp_chunk_bytes(n.id, 4));
+  for (int l = n.NL - 2; l >= 1; --l) for (int c = 0; c < 4; ++c) b.push_back(af_mlp_chunk_bytes(n.id, 1));
+  if (n.dx0) b.push_back(af_mlp_chunk_bytes(n.id, 5));
+  auto same = [](const std::vector<AfChunk>& plan, const std::vector<int>& want) {
+    if (plan.size() != want.size()) return false;
+    uint32_t off = 0;
+    for (size_t i = 0; i < plan.size(); ++i) { if (plan[i].off != off || (int)plan[i].bytes != want[i]) return false; off += plan[i].bytes; }
+    return true;
+  };
+  return same(n.fchunks, f) && same(n.bchunks, b);
 }
 
 int shape_tiles(int shape, int& To, int& Ti) {
@@ -555,7 +575,10 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
     describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, 8, AF_IN_PE3, 5, 1, 0u, false);
   }
   size_t fc = 0, bc = 0, biasc = 0, pc = 0;
-  for (NetDesc& n : h->nets) if (n.used) { n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc); }
+  for (NetDesc& n : h->nets) if (n.used) {
+    n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc);
+    if (!check_chunk_plan(n)) { h->fail(AF_EINVAL, "weight-image plan does not match the kernels' chunk sequence"); return die(AF_EINVAL); }
+  }
   fc += AF_CHUNK_MAX / 4; bc += AF_CHUNK_MAX / 4;   // every LDS stage copies a full 64 KB buffer: keep the over-read in bounds
   h->total_params = pc; h->img_f_floats = fc; h->img_b_floats = bc; h->bias_floats = biasc;
   CCHK(dalloc(&h->params, pc)); CCHK(dalloc(&h->adam_m, pc)); CCHK(dalloc(&h->adam_v, pc));

@@ -24,6 +24,20 @@ struct NsMap2  { static constexpr int NL = 4, IN = AF_IN_XYT, K0G = 1, PEG = 0, 
 struct NsAtlas { static constexpr int NL = 8, IN = AF_IN_PE2, K0G = 5, PEG = 5, OUT = 3; static constexpr unsigned SKIP = (1u << 4) | (1u << 7);   static constexpr bool DX0 = true;  };
 struct NsAlpha { static constexpr int NL = 8, IN = AF_IN_PE3, K0G = 4, PEG = 4, OUT = 1; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 
+// Byte sizes of the weight chunks, in stream order (host.hip plan_images lays the images out contiguously in
+// exactly this order, so a chunk's address is the previous chunk's address plus its size: no table lookups
+// inside the kernels).  A k-group of an Mpad-row image is 2*Mpad*16 bytes; sizes round up to 4 KB.
+constexpr int af_round4k(int b) { return (b + 4095) / 4096 * 4096; }
+template <class NS> struct ChunkBytes {
+  static constexpr int L0   = af_round4k(NS::K0G * 2 * AF_HID * 16);                                            // forward layer 0
+  static constexpr int HID  = 8 * 2 * AF_HID * 16;                                                            // a quarter of a 256x256 layer = 64 KB
+  static constexpr int SKIP = af_round4k(NS::PEG * 2 * AF_HID * 16);                                            // PE columns of a skip layer
+  static constexpr int LAST = af_round4k((32 + (((NS::SKIP >> (NS::NL - 1)) & 1) ? NS::PEG : 0)) * 2 * 32 * 16);   // forward output layer (Mpad 32)
+  static constexpr int BLAST = 2 * AF_HID * 16;                                                               // backward output layer: one k-group
+  static constexpr int BL0  = 32 * 2 * 64 * 16;                                                               // backward layer 0 (Mpad 64 PE slots)
+};
+static_assert(ChunkBytes<NsMap1>::HID == AF_CHUNK_MAX && ChunkBytes<NsAtlas>::BL0 == AF_CHUNK_MAX, "chunk = LDS buffer");
+
 // acc[T] += A(image in LDS) * b[B0 + 4*g + p]  for NG k-groups; a_lds already includes the lane offset
 // (h*MPAD + j)*16.  NP < 4 skips reduction indices that are structurally zero.  hook(g) is called once per
 // k-group right after that group's A-fragment reads were issued: work placed there (LDS-DMA issue of the
@@ -31,7 +45,7 @@ struct NsAlpha { static constexpr int NL = 8, IN = AF_IN_PE3, K0G = 4, PEG = 4, 
 // instead of in front of an empty matrix pipe.
 template <int G> struct GIdx { static constexpr int value = G; };
 
-template <int MT, int NG, int B0, int NP, int NB, class Hook, int... Gs>
+template <int MT, int NG, int B0, int NP, bool ZI, int NB, class Hook, int... Gs>
 AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook& hook, std::integer_sequence<int, Gs...>) {
   constexpr int MPAD = MT * 32;
   f32x4 a[2][MT];
@@ -51,16 +65,23 @@ AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int T = 0; T < MT; ++T)
+      for (int T = 0; T < MT; ++T) {
+        if constexpr (ZI && g == 0) {
+          if (p == 0) { const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][T][0], b[B0], z, 0, 0, 0); continue; }
+        }
         acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][T][p], b[B0 + g * 4 + p], acc[T], 0, 0, 0);
+      }
     }
     if constexpr (!(AF_ABL & 16)) __builtin_amdgcn_sched_barrier(0);     // keep each group's DMA / stores inside its own MFMA shadow
   };
   (step(GIdx<Gs>{}), ...);
 }
-template <int MT, int NG, int B0, int NP, int NB, class Hook>
+// ZI: the accumulators start at zero — the first MFMA of each takes an inline-constant 0 as C instead of
+// a previously zeroed register block (saves MT*16 v_accvgpr_write per layer in the backward chain).
+template <int MT, int NG, int B0, int NP, bool ZI = false, int NB, class Hook>
 AF_DEV void mm_block(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook&& hook) {
-  mm_block_impl<MT, NG, B0, NP>(acc, b, a_lds, hook, std::make_integer_sequence<int, NG>{});
+  mm_block_impl<MT, NG, B0, NP, ZI>(acc, b, a_lds, hook, std::make_integer_sequence<int, NG>{});
 }
 
 // Double-buffered LDS stream of weight chunks shared by the four waves of the workgroup.  Every stage moves
@@ -68,31 +89,34 @@ AF_DEV void mm_block(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds,
 // the over-read stays in bounds — which keeps the issue sites branch-free: two LDS-DMA instructions per
 // k-group ride in the shadow of that group's 32 MFMAs.
 struct ChunkStream {
-  const char* img; const AfChunk* tab; char* smem; int tid, wave, cidx, n;
-  const char* p_src; char* p_dst; int p_it;            // chunk being staged (issued incrementally)
-  AF_DEV void begin_stage(int c) {
-    const AfChunk d = tab[c < n ? c : 0];              // past the end: harmless re-read of chunk 0 into the idle buffer
-    p_src = img + d.off + tid * 16; p_dst = smem + (c & 1) * AF_CHUNK_MAX + wave * 1024;
-    p_it = 0;
-  }
+  const char* src;                                     // this lane's 16-B column of the chunk being staged
+  char* smem; int wave, cidx;
+  char* p_dst; int p_it;                               // chunk being staged (issued incrementally)
+  AF_DEV void begin_stage(int c) { p_dst = smem + (c & 1) * AF_CHUNK_MAX + wave * 1024; p_it = 0; }
   AF_DEV void issue2() {
     if constexpr (AF_ABL & 2) { p_it += 2; return; }
-    af_glds16(p_src + p_it * 4096, p_dst + p_it * 4096);
-    af_glds16(p_src + p_it * 4096 + 4096, p_dst + p_it * 4096 + 4096);
+    af_glds16(src + p_it * 4096, p_dst + p_it * 4096);
+    af_glds16(src + p_it * 4096 + 4096, p_dst + p_it * 4096 + 4096);
     p_it += 2;
   }
-  AF_DEV void start() { cidx = 0; begin_stage(0); }
-  // Make chunk `cidx` visible to every wave (and know every wave is done with chunk cidx-1), then arm the
-  // staging of chunk cidx+1 into the buffer chunk cidx-1 used.  Returns the LDS base of chunk cidx.
-  AF_DEV const char* next() {
+  AF_DEV void start(const void* img, int tid) { src = (const char*)img + tid * 16; cidx = 0; begin_stage(0); }
+  // Make chunk `cidx` (BYTES long) visible to every wave (and know every wave is done with chunk cidx-1), then
+  // arm the staging of chunk cidx+1 — which starts BYTES further on — into the buffer chunk cidx-1 used.
+  // Returns the LDS base of chunk cidx.  After the last chunk the stream stages 64 KB of whatever follows
+  // (the image buffers are padded for that) into the idle buffer: harmless, and the issue sites stay branch-free.
+  template <int BYTES> AF_DEV const char* next() {
     while (p_it < 16) issue2();
     if constexpr (!(AF_ABL & 4)) { af_wait_vm0(); __syncthreads(); }
     const int cur = cidx;
     cidx = cur + 1;
+    src += BYTES;
     begin_stage(cidx);
     return smem + (cur & 1) * AF_CHUNK_MAX;
   }
 };
+
+// max(z, 0) as ONE v_max_f32 (the C-level fmaxf adds a canonicalising v_max in front)
+AF_DEV float af_relu(float z) { float v; asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(z)); return v; }
 
 AF_DEV void init_bias(f32x16 (&acc)[8], __amdgpu_buffer_rsrc_t rb, int layer, int h) {
 #pragma unroll
@@ -109,8 +133,9 @@ AF_DEV void init_bias(f32x16 (&acc)[8], __amdgpu_buffer_rsrc_t rb, int layer, in
 // tile [256][32].
 template <int T>
 AF_DEV void store_tile_part(const float (&v)[128], __amdgpu_buffer_rsrc_t r, int voff) {
+  // the 128-B steps between p = 0..3 ride in the instruction's immediate offset: one soffset per (T, q)
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) af_bs32(v[T * 16 + rr], r, voff, (32 * T + (rr & 3) + 8 * (rr >> 2)) * 128);
+  for (int rr = 0; rr < 16; ++rr) af_bs32(v[T * 16 + rr], r, voff + (rr & 3) * 128, (32 * T + 8 * (rr >> 2)) * 128);
 }
 
 // Deferred stores of one 32x256 block: one feature tile per k-group of the following GEMM block.
@@ -132,8 +157,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
 
-  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks, nullptr, nullptr, 0};
-  cs.start();
+  using CB = ChunkBytes<NS>;
+  ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
+  cs.start(a.wimg, tid);
 
   const auto rb = af_rsrc(a.bias, NS::NL * AF_HID * 4);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     }
     if constexpr (TRAIN && NS::PEG > 0) {
       if (live) {   // PE features in reference feature order, T-layout [64][32], for the dW GEMMs
-        const auto r = af_rsrc(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+        const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
         if constexpr (NS::IN == AF_IN_PE2) {
 #pragma unroll
           for (int g = 0; g < 5; ++g)
@@ -190,21 +216,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   TileStore ts{af_rsrc(a.acts, 0), voff_t};
 
   auto relu_out = [&](int l) {               // acc -> in[] = relu(Z_l) = X_{l+1}; its stores are deferred
+    // ReLU sign bits, 32 per word: element e = (T&1)*16 + r of word T>>1 sits at bit 31-e.  One v_alignbit
+    // shifts the sign of (0 - v) in: set exactly when v > 0 (0 - (+0) = +0), no VCC round trip.
     uint32_t mk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int T = 0; T < 8; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = fmaxf(acc[T][r], 0.f);
+        const float v = af_relu(acc[T][r]);
         in[T * 16 + r] = v;
-        if (TRAIN) mk[T >> 1] |= (v > 0.f ? 1u : 0u) << ((T & 1) * 16 + r);
+        if (TRAIN) mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __builtin_bit_cast(uint32_t, 0.f - v), 31);
       }
     if constexpr (TRAIN) {
       if (live) {
         u32x4 m4 = {mk[0], mk[1], mk[2], mk[3]};
         *(u32x4*)(a.masks + (((size_t)l * a.nt_stride + tile) * 64 + lane) * 4) = m4;
       }
-      ts.r = af_rsrc(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+      ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   // ---- layer 0
   init_bias(acc, rb, 0, h);
   {
-    const char* buf = cs.next();
+    const char* buf = cs.next<CB::L0>();
     mm_block<8, NS::K0G, 0, 4>(acc, pe, buf + a_off8, hook_dma);
   }
   relu_out(0);
@@ -224,12 +252,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   // ---- hidden layers 1 .. NL-2
   for (int l = 1; l <= NS::NL - 2; ++l) {
     init_bias(acc, rb, l, h);
-    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
-    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
-    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
-    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
     if constexpr (NS::SKIP != 0) {
-      if ((NS::SKIP >> l) & 1) { const char* buf = cs.next(); mm_block<8, NS::PEG, 0, 4>(acc, pe, buf + a_off8, hook_dma); }
+      if ((NS::SKIP >> l) & 1) { const char* buf = cs.next<CB::SKIP>(); mm_block<8, NS::PEG, 0, 4>(acc, pe, buf + a_off8, hook_dma); }
     }
     relu_out(l);
   }
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
       const f32x4 b4 = af_bl128(rb, h * 16, ((NS::NL - 1) * AF_HID + 8 * q) * 4);
       acc1[0][q * 4 + 0] = b4[0]; acc1[0][q * 4 + 1] = b4[1]; acc1[0][q * 4 + 2] = b4[2]; acc1[0][q * 4 + 3] = b4[3];
     }
-    const char* buf = cs.next();
+    const char* buf = cs.next<CB::LAST>();
     const char* al = buf + (h * 32 + j) * 16;
     mm_block<1, 32, 0, 4>(acc1, in, al, hook_dma_store);
     if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) mm_block<1, NS::PEG, 0, 4>(acc1, pe, al + 32 * 2 * 32 * 16, hook_dma);
@@ -273,8 +301,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
 
-  ChunkStream cs{(const char*)a.wimg, a.chunks, smem, tid, wave, 0, a.nchunks, nullptr, nullptr, 0};
-  cs.start();
+  using CB = ChunkBytes<NS>;
+  ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
+  cs.start(a.wimg, tid);
 
   float dzl[4];
   {
@@ -294,12 +323,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   float in[128];
   TileStore ts{af_rsrc(a.dz, 0), voff_t};
 
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
-  };
   auto mask_out = [&](int l) {      // acc = dX_l; mask with sign bits of X_l (masks[l-1]) -> in[] = dZ_{l-1}
     const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.nt_stride + tile) * 64 + lane) * 4);
     const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
@@ -308,23 +331,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         in[T * 16 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
-                                                   (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 1], (T & 1) * 16 + r, 1));
-    ts.r = af_rsrc(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+                                                   (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 1], 31 - ((T & 1) * 16 + r), 1));
+    ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); ts.template part<decltype(gi)::value>(in); };
 
   // ---- output layer: K = 8 (one group), only p < OUT non-zero
-  zero_acc();
-  { const char* buf = cs.next(); mm_block<8, 1, 0, NS::OUT>(acc, dzl, buf + a_off8, hook_dma); }
+  { const char* buf = cs.next<CB::BLAST>(); mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, buf + a_off8, hook_dma); }
   mask_out(NS::NL - 1);
 
   for (int l = NS::NL - 2; l >= 1; --l) {
-    zero_acc();
-    { const char* buf = cs.next(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
-    { const char* buf = cs.next(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
-    { const char* buf = cs.next(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
-    { const char* buf = cs.next(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4, true>(acc, in, buf + a_off8, hook_dma_store); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
+    { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 96, 4>(acc, in, buf + a_off8, hook_dma); }
     mask_out(l);
   }
 
@@ -332,12 +353,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
     // dPE = W_0^T dZ_0  (M = 64 padded PE features, K = 256), then chain through sin/cos to the 2-D input
     static_assert(NS::IN == AF_IN_PE2, "input gradient is only needed for the atlas net");
     f32x16 acc2[2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[T][r] = 0.f;
-    { const char* buf = cs.next(); mm_block<2, 32, 0, 4>(acc2, in, buf + (h * 64 + j) * 16, hook_dma_store); }
-    const auto r = af_rsrc(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+    { const char* buf = cs.next<CB::BL0>(); mm_block<2, 32, 0, 4, true>(acc2, in, buf + (h * 64 + j) * 16, hook_dma_store); }
+    const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
     float dx0 = 0.f, dx1 = 0.f;
 #pragma unroll
     for (int g = 0; g < 5; ++g) {
@@ -396,6 +413,23 @@ extern "C" int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s) {
     default: return -1;
   }
   return (int)hipGetLastError();
+}
+
+// The chunk sizes the kernels assume, for the host planner to check its layout against:
+// which = 0 fwd layer 0, 1 hidden quarter, 2 skip columns, 3 fwd output layer, 4 bwd output layer, 5 bwd layer 0.
+extern "C" int af_mlp_chunk_bytes(int net, int which) {
+  auto pick = [&](auto ns) -> int {
+    using CB = ChunkBytes<decltype(ns)>;
+    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::LAST, CB::BLAST, CB::BL0};
+    return which >= 0 && which < 6 ? v[which] : -1;
+  };
+  switch (net) {
+    case AF_NET_MAP1:  return pick(NsMap1{});
+    case AF_NET_MAP2:  return pick(NsMap2{});
+    case AF_NET_ATLAS: return pick(NsAtlas{});
+    case AF_NET_ALPHA: return pick(NsAlpha{});
+    default: return -1;
+  }
 }
 
 extern "C" int af_mlp_init() {   // opt in to 128 KB dynamic LDS for every instantiation

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dch, ch.size() * sizeof(AfChunk))); CK(hipMemcpy(dch, ch.data(), ch.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
   std::vector<float> w(off / 4); for (auto& x : w) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
   CK(hipMemcpy(img, w.data(), off, hipMemcpyHostToDevice));
-  FwdArgs fa{}; fa.wimg = img; fa.chunks = dch; fa.bias = bias; fa.in = in; fa.out = out; fa.acts = acts; fa.masks = masks;
+  FwdArgs fa{}; fa.wimg = img; fa.chunks = dch; fa.in1 = nullptr; fa.bias = bias; fa.in = in; fa.out = out; fa.acts = acts; fa.masks = masks;
   fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.nchunks = (int)ch.size();
   // backward chunk order: [8K, 16 x 64K]
   std::vector<AfChunk> bch; off = 0; bch.push_back({off, 16384}); off += 16384;
