@@ -158,7 +158,7 @@ def load_library(path=None):
         "af_set_debug": (i32, [vp, i32]),
         "af_get_last_grads": (i32, [vp, i32, vp, sz]),
         "af_set_timing": (i32, [vp, i32]),
-        "af_get_timing": (i32, [vp, vp, vp, i32]),
+        "af_get_timing": (i32, [vp, vp, vp, vp, i32]),
         "af_step_work": (i32, [vp, i32, C.POINTER(i64 * 4), C.POINTER(C.c_double)]),
         "af_loss_width": (i32, [vp]),
         "af_config_size": (sz, []),
@@ -222,8 +222,7 @@ class AtlasFit:
     LOSS_NAMES = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total", "valid_fwd", "valid_bwd")
     LOSS_NAMES_TWO_LAYER = ("rgb", "gradient", "rigidity1", "rigidity2", "global_rigidity1", "global_rigidity2", "flow1", "flow2",
                             "flow_alpha", "alpha_bootstrapping", "sparsity", "total", "valid_fwd", "valid_bwd", "_", "_")
-    TIMING_NAMES = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam",
-                    "fwd_map2", "fwd_alpha", "bwd_map2", "bwd_alpha")
+    TIMING_NAMES = ("prep", "fwd_1", "fwd_2", "loss", "bwd_1", "bwd_2", "dw", "adam")
 
     def __init__(self, cfg, device=0):
         self.lib = load_library()
@@ -354,9 +353,10 @@ class AtlasFit:
         self._chk(self.lib.af_set_timing(self.h, int(mask) if not isinstance(mask, bool) else (0xFFFF if mask else 0)))
 
     def timing(self, reset=True):
-        ms = np.zeros(16, np.float64); cnt = np.zeros(16, np.int64)
-        self._chk(self.lib.af_get_timing(self.h, _ptr(ms), _ptr(cnt), int(reset)))
-        return {n: (float(m), int(c)) for n, m, c in zip(self.TIMING_NAMES, ms, cnt)}
+        """{launch class: (milliseconds, launches, algorithmic FLOPs)} accumulated since the last reset."""
+        ms = np.zeros(16, np.float64); cnt = np.zeros(16, np.int64); fl = np.zeros(16, np.float64)
+        self._chk(self.lib.af_get_timing(self.h, _ptr(ms), _ptr(cnt), _ptr(fl), int(reset)))
+        return {n: (float(m), int(c), float(f)) for n, m, c, f in zip(self.TIMING_NAMES, ms, cnt, fl)}
 
     def step_work(self, it):
         """(rows per net indexed by NET_*, fwd+bwd FLOPs) of one loop iteration."""

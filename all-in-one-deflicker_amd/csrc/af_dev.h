@@ -78,6 +78,10 @@ struct BwdArgs {
   int nchunks;
 };
 
+// one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip
+struct MultiFwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; FwdArgs a[AF_MAX_NETS]; };
+struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; };
+
 struct DwJob {
   const float* A; const float* B;     // T-layout tensors (dZ_l and X_l)
   uint32_t a_stride, b_stride;        // floats per row tile

@@ -17,8 +17,8 @@
 #include "elem.h"
 
 extern "C" {
-int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s);
-int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s);
+int af_launch_fwd_multi(MultiFwd* m, int train, hipStream_t s);
+int af_launch_bwd_multi(MultiBwd* m, hipStream_t s);
 int af_mlp_init();
 int af_mlp_chunk_bytes(int net, int which);
 int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s);
@@ -92,7 +92,7 @@ struct af_handle {
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
-  std::vector<TimedEv> evs; double t_ms[16] = {0}; long long t_cnt[16] = {0};
+  std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
     char buf[512];
@@ -108,13 +108,11 @@ struct af_handle {
 
 namespace {
 
-// timing classes (include/atlasfit.h: af_get_timing)
-enum { T_PREP = 0, T_FWD_MAP1 = 1, T_FWD_ATLAS = 2, T_LOSS = 3, T_BWD_ATLAS = 4, T_BWD_MAP1 = 5, T_DW = 6, T_ADAM = 7,
-       T_FWD_MAP2 = 8, T_FWD_ALPHA = 9, T_BWD_MAP2 = 10, T_BWD_ALPHA = 11 };
-const int kFwdClass[AF_MAX_NETS] = {T_FWD_MAP1, T_FWD_ATLAS, T_FWD_MAP2, T_FWD_ALPHA};
-const int kBwdClass[AF_MAX_NETS] = {T_BWD_MAP1, T_BWD_ATLAS, T_BWD_MAP2, T_BWD_ALPHA};
-// algorithmic fwd + dX + dW FLOPs per MLP row (BASELINE.md §3 / SURVEY.md §8d), indexed by af_net
-const double kFlopRow[AF_MAX_NETS] = {1579008.0, 2466784.0, 792576.0, 2391552.0};
+// timing classes (include/atlasfit.h: af_get_timing): the two forward and the two backward launches of a step
+enum { T_PREP = 0, T_FWD_1 = 1, T_FWD_2 = 2, T_LOSS = 3, T_BWD_1 = 4, T_BWD_2 = 5, T_DW = 6, T_ADAM = 7 };
+// algorithmic FLOPs per MLP row (BASELINE.md §3 / SURVEY.md §8d), indexed by af_net: forward (== dW) and dX chain
+const double kFlopFwd[AF_MAX_NETS] = {526848.0, 829168.0, 264704.0, 802304.0};
+const double kFlopDx[AF_MAX_NETS]  = {525312.0, 808448.0, 263168.0, 786944.0};
 
 template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
@@ -351,8 +349,8 @@ BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
 
 struct Timer {
   af_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr;
-  Timer(af_handle* h_, int c) : h(h_), cls(c) {
-    if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); }
+  Timer(af_handle* h_, int c, double flops = 0.0) : h(h_), cls(c) {
+    if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); h->t_flops[cls] += flops; }
   }
   ~Timer() { if (on()) { (void)hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); } }
   bool on() const { return (h->timing >> cls) & 1u; }
@@ -387,20 +385,51 @@ int repack(af_handle* h, Sched& sc) {
 
 bool glob_on(const af_config& c, int iter) { return c.include_global_rigidity_loss && iter <= c.stop_global_rigidity; }
 
-int launch_fwd(af_handle* h, int net, const FwdArgs& fa, bool train) {
-  Timer t(h, kFwdClass[net]);
-  LCHK(af_launch_fwd(net, train ? 1 : 0, &fa, h->stream));
+// rows of a part that carry real data (the last tile of a net may be padded)
+double part_rows(int tile0, int NT, int rows_total) { return (double)std::max(0, std::min(NT * 32, rows_total) - tile0 * 32); }
+
+struct FwdPart { int net; FwdArgs a; int rows_total; };
+struct BwdPart { int net; BwdArgs a; int rows_total; };
+
+// One forward / backward launch over independent parts (mlp.hip k_mlp_*_multi); empty parts are dropped.
+int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool train) {
+  MultiFwd m{}; double fl = 0;
+  for (const FwdPart& p : parts) {
+    if (p.a.NT <= p.a.tile0) continue;
+    m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
+    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * kFlopFwd[p.net];
+  }
+  if (m.n == 0) return 0;
+  Timer t(h, cls, fl);
+  LCHK(af_launch_fwd_multi(&m, train ? 1 : 0, h->stream));
   return 0;
 }
-int launch_bwd(af_handle* h, int net, const BwdArgs& ba) {
-  Timer t(h, kBwdClass[net]);
-  LCHK(af_launch_bwd(net, &ba, h->stream));
+int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
+  MultiBwd m{}; double fl = 0;
+  for (const BwdPart& p : parts) {
+    if (p.a.NT <= p.a.tile0) continue;
+    m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
+    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * kFlopDx[p.net];
+  }
+  if (m.n == 0) return 0;
+  Timer t(h, cls, fl);
+  LCHK(af_launch_bwd_multi(&m, h->stream));
   return 0;
+}
+FwdArgs tile_range(FwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
+BwdArgs tile_range(BwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
+
+// The mapping batch splits into whole rounds of the chip (ncu workgroups x 4 row tiles) and a remainder.  The
+// whole rounds must contain every row the atlas chain depends on (the first `dep_rows` rows); if they do not,
+// the batch is not split.
+int whole_round_tiles(const af_handle* h, int NT, int dep_rows) {
+  const int round = h->ncu * 4, t1 = NT / round * round;
+  return t1 * 32 >= dep_rows ? t1 : NT;
 }
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
-int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk) {
-  { Timer t(h, T_DW); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
+int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops) {
+  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
   {
     Timer t(h, T_ADAM);
     AdamArgs a{};
@@ -446,9 +475,20 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     p.coords = M.coords; p.x0_tile = M.x0_tile; p.samples = h->samples; p.counts = h->counts;
     LCHK(af_launch_prep(&p, h->stream));
   }
+  // Launch 1: the whole rounds of the mapping batch (they hold the 3N rows the atlas reads).  Launch 2: the atlas
+  // chain plus the mapping remainder — rigidity / flow rows nothing in this launch depends on — in the CUs the
+  // atlas workgroups leave idle.  The backward pass mirrors it (the remainder needs no atlas gradient).
   int rc;
-  if ((rc = launch_fwd(h, AF_NET_MAP1, fwd_args(h, M, M.coords, M.out_buf, NT_map, true), true)) != 0) return rc;
-  if ((rc = launch_fwd(h, AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true), true)) != 0) return rc;
+  const int T1 = whole_round_tiles(h, NT_map, 3 * N);
+  const FwdArgs fm = fwd_args(h, M, M.coords, M.out_buf, NT_map, true);
+  if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, tile_range(fm, 0, T1), nseg * N}}, true)) != 0) return rc;
+  // Workgroup i + ncu is dispatched behind workgroup i (measured: two workgroups over one round cost a full atlas
+  // chain when they queue behind atlas workgroups, nothing when they queue behind the shorter mapping ones), so the
+  // remainder's first E workgroups lead the grid, E = the number of workgroups beyond one round.
+  const int T2 = std::min(NT_map, T1 + 4 * std::max(0, (NT_atlas + 3) / 4 + (NT_map - T1 + 3) / 4 - h->ncu));
+  if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_MAP1, tile_range(fm, T1, T2), nseg * N},
+                                    {AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true), 3 * N},
+                                    {AF_NET_MAP1, tile_range(fm, T2, NT_map), nseg * N}}, true)) != 0) return rc;
   {
     Timer t(h, T_LOSS);
     LossArgs l{};
@@ -460,9 +500,15 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     LCHK(af_launch_loss_single(&l, h->stream));
   }
   h->adam_step += 1;
-  { BwdArgs b = bwd_args(h, A, NT_atlas); b.din0 = M.dout; b.nrows = 3 * N; if ((rc = launch_bwd(h, AF_NET_ATLAS, b)) != 0) return rc; }
-  if ((rc = launch_bwd(h, AF_NET_MAP1, bwd_args(h, M, NT_map))) != 0) return rc;
-  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256);
+  {
+    BwdArgs ba = bwd_args(h, A, NT_atlas); ba.din0 = M.dout; ba.nrows = 3 * N;
+    const BwdArgs bm = bwd_args(h, M, NT_map);
+    if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_MAP1, tile_range(bm, T1, T2), nseg * N}, {AF_NET_ATLAS, ba, 3 * N},
+                                      {AF_NET_MAP1, tile_range(bm, T2, NT_map), nseg * N}})) != 0) return rc;
+    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_MAP1, tile_range(bm, 0, T1), nseg * N}})) != 0) return rc;
+  }
+  const double dwf = (double)nseg * N * kFlopFwd[AF_NET_MAP1] + 3.0 * N * kFlopFwd[AF_NET_ATLAS];
+  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
 }
 
 // One iteration of the fg/bg dual-atlas loop (stage1_neural_atlas_seg.py:193-315).
@@ -490,15 +536,19 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     p.coords2 = M2.coords; p.x0_tile2 = M2.x0_tile; p.coordsA = AL.coords; p.d_global2 = c.global_rigidity_derivative_amount_bg;
     LCHK(af_launch_prep(&p, h->stream));
   }
+  // Launch 1: alpha, mapping1, mapping2 (longest chains first, so the launch drains on the short ones).
+  // Launch 2: the atlas chain — rows [0,3N) = uv1*0.5+0.5 (foreground quadrant), [3N,6N) = uv2*0.5-0.5
+  // (background), :229-232 — topped up to whole rounds of the chip with the last alpha row tiles.
   int rc;
-  if ((rc = launch_fwd(h, AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true), true)) != 0) return rc;
-  if ((rc = launch_fwd(h, AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true), true)) != 0) return rc;
-  if ((rc = launch_fwd(h, AF_NET_ALPHA, fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true), true)) != 0) return rc;
-  {   // atlas rows: [0,3N) = uv1*0.5+0.5 (foreground quadrant), [3N,6N) = uv2*0.5-0.5 (background), :229-232
-    FwdArgs fa = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true);
-    fa.in1 = M2.out_buf; fa.split_row = 3 * N;
-    if ((rc = launch_fwd(h, AF_NET_ATLAS, fa, true)) != 0) return rc;
-  }
+  const int wg_atlas = (NT_atlas + 3) / 4, pad = (h->ncu - wg_atlas % h->ncu) % h->ncu;
+  const int T_al = std::max(0, NT_alpha - 4 * pad);                 // alpha tiles [T_al, NT_alpha) ride with the atlas
+  const FwdArgs fal = fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true);
+  FwdArgs fat = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true);
+  fat.in1 = M2.out_buf; fat.split_row = 3 * N;
+  if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_ALPHA, tile_range(fal, 0, T_al), 5 * N},
+                                    {AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true), nseg * N},
+                                    {AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true), nseg * N}}, true)) != 0) return rc;
+  if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fat, 6 * N}, {AF_NET_ALPHA, tile_range(fal, T_al, NT_alpha), 5 * N}}, true)) != 0) return rc;
   {
     Timer t(h, T_LOSS);
     LossSegArgs l{};
@@ -515,15 +565,16 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     LCHK(af_launch_loss_seg(&l, h->stream));
   }
   h->adam_step += 1;
-  {
-    BwdArgs b = bwd_args(h, A, NT_atlas);
-    b.din0 = M1.dout; b.din1 = M2.dout; b.split_row = 3 * N; b.nrows = 6 * N;
-    if ((rc = launch_bwd(h, AF_NET_ATLAS, b)) != 0) return rc;
+  {   // the mapping chains need the atlas chain's input gradient (rows < 3N): atlas (+ alpha top-up) first
+    BwdArgs ba = bwd_args(h, A, NT_atlas);
+    ba.din0 = M1.dout; ba.din1 = M2.dout; ba.split_row = 3 * N; ba.nrows = 6 * N;
+    const BwdArgs bal = bwd_args(h, AL, NT_alpha);
+    if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_ATLAS, ba, 6 * N}, {AF_NET_ALPHA, tile_range(bal, T_al, NT_alpha), 5 * N}})) != 0) return rc;
+    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, bwd_args(h, M1, NT_map), nseg * N},
+                                      {AF_NET_MAP2, bwd_args(h, M2, NT_map), nseg * N}})) != 0) return rc;
   }
-  if ((rc = launch_bwd(h, AF_NET_MAP1, bwd_args(h, M1, NT_map))) != 0) return rc;
-  if ((rc = launch_bwd(h, AF_NET_MAP2, bwd_args(h, M2, NT_map))) != 0) return rc;
-  if ((rc = launch_bwd(h, AF_NET_ALPHA, bwd_args(h, AL, NT_alpha))) != 0) return rc;
-  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256);
+  const double dwf = (double)nseg * N * (kFlopFwd[AF_NET_MAP1] + kFlopFwd[AF_NET_MAP2]) + 6.0 * N * kFlopFwd[AF_NET_ATLAS] + 5.0 * N * kFlopFwd[AF_NET_ALPHA];
+  return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
 }
 
 }  // namespace
@@ -740,10 +791,15 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
 
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
 int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
-int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, int reset) {
+int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset) {
   if (!h) return AF_EINVAL;
   (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); drain_timers(h);
-  for (int i = 0; i < 16; ++i) { if (ms16) ms16[i] = h->t_ms[i]; if (counts16) counts16[i] = h->t_cnt[i]; if (reset) { h->t_ms[i] = 0; h->t_cnt[i] = 0; } }
+  for (int i = 0; i < 16; ++i) {
+    if (ms16) ms16[i] = h->t_ms[i];
+    if (counts16) counts16[i] = h->t_cnt[i];
+    if (flops16) flops16[i] = h->t_flops[i];
+    if (reset) { h->t_ms[i] = 0; h->t_cnt[i] = 0; h->t_flops[i] = 0; }
+  }
   return AF_OK;
 }
 
@@ -788,11 +844,11 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       p.half_main = half_main; p.t = (float)((double)f / (F / 2.0) - 1.0);
       p.coords = M.coords; p.x0_tile = M.x0_tile;
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
-      if ((rc = launch_fwd(h, net, fwd_args(h, M, M.coords, M.out_buf, NT, true), true)) != 0) break;
+      if ((rc = launch_fwd(h, T_FWD_1, {{net, fwd_args(h, M, M.coords, M.out_buf, NT, true), NB}}, true)) != 0) break;
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      if ((rc = launch_bwd(h, net, bwd_args(h, M, NT))) != 0) break;
-      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256);
+      if ((rc = launch_bwd(h, T_BWD_2, {{net, bwd_args(h, M, NT), NB}})) != 0) break;
+      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * kFlopFwd[net]);
     }
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
@@ -880,7 +936,7 @@ int af_step_work(const af_handle* h, int iter, int64_t rows4[4], double* flops) 
   const int64_t nseg = glob_on(h->cfg, iter) ? 9 : 7, N = h->N;
   int64_t r[4] = {nseg * N, (h->seg ? 6 : 3) * N, h->seg ? nseg * N : 0, h->seg ? 5 * N : 0};
   double f = 0;
-  for (int i = 0; i < 4; ++i) { if (rows4) rows4[i] = r[i]; f += (double)r[i] * kFlopRow[i]; }
+  for (int i = 0; i < 4; ++i) { if (rows4) rows4[i] = r[i]; f += (double)r[i] * (2.0 * kFlopFwd[i] + kFlopDx[i]); }
   if (flops) *flops = f;
   return AF_OK;
 }
@@ -907,7 +963,7 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
   HCHK(hipMemcpyAsync(h->r_coords, in, (size_t)rows * 16, hipMemcpyHostToDevice, h->stream));
   FwdArgs fa = fwd_args(h, h->nets[net], h->r_coords, h->r_uv, NT, false);
   if (h->nets[net].in_kind != AF_IN_XYT) { fa.in_scale = 1.f; fa.in_shift0 = 0.f; fa.in_shift1 = 0.f; }
-  LCHK(af_launch_fwd(net, 0, &fa, h->stream));
+  { int rc2 = launch_fwd(h, T_FWD_1, {{net, fa, rows}}, false); if (rc2) return rc2; }
   HCHK(hipMemcpyAsync(out, h->r_uv, (size_t)rows * 16, hipMemcpyDeviceToHost, h->stream));
   HCHK(hipStreamSynchronize(h->stream));
   return AF_OK;
@@ -925,19 +981,18 @@ int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out) {
   const float t = (float)((double)frame / (F / 2.0) - 1.0);     // evaluate.py:656 computes t in Python floats
   LCHK(af_launch_frame_coords(h->r_coords, h->cfg.resx, h->cfg.resy, half_main, t, NT * 32, h->stream));
   FwdArgs fm = fwd_args(h, h->nets[AF_NET_MAP1], h->r_coords, h->r_uv, NT, false);
-  LCHK(af_launch_fwd(AF_NET_MAP1, 0, &fm, h->stream));
   if (!h->seg) {
+    if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, fm, npix}}, false)) != 0) return rc;
     FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false);
-    LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
+    if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fa, npix}}, false)) != 0) return rc;
     LCHK(af_launch_frame_finish(h->r_t, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
   } else {   // evaluate.py:302-337
     FwdArgs f2 = fwd_args(h, h->nets[AF_NET_MAP2], h->r_coords, h->r_uv2, NT, false);
-    LCHK(af_launch_fwd(AF_NET_MAP2, 0, &f2, h->stream));
     FwdArgs fl = fwd_args(h, h->nets[AF_NET_ALPHA], h->r_coords, h->r_al, NT, false);
-    LCHK(af_launch_fwd(AF_NET_ALPHA, 0, &fl, h->stream));
+    if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_ALPHA, fl, npix}, {AF_NET_MAP1, fm, npix}, {AF_NET_MAP2, f2, npix}}, false)) != 0) return rc;
     FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, 2 * NT, false);
     fa.in1 = h->r_uv2; fa.split_row = NT * 32;
-    LCHK(af_launch_fwd(AF_NET_ATLAS, 0, &fa, h->stream));
+    if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fa, 2 * NT * 32}}, false)) != 0) return rc;
     LCHK(af_launch_frame_finish_seg(h->r_t, h->r_al, (size_t)NT * 32, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
   }
   const int nblk = (npix + 255) / 256;

@@ -147,12 +147,11 @@ struct TileStore {
 };
 
 template <class NS, bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-  int tile = a.tile0 + blockIdx.x * 4 + wave;
+  int tile = a.tile0 + wg * 4 + wave;
   const bool live = tile < a.NT;
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
@@ -291,12 +290,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 // and accumulates dL/d(uv) onto the mapping net's output gradient (the detached skip inputs carry no
 // gradient: implicit_neural_networks.py:69).
 template <class NS>
-__global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-  int tile = a.tile0 + blockIdx.x * 4 + wave;
+  int tile = a.tile0 + wg * 4 + wave;
   const bool live = tile < a.NT;
   if (!live) tile = a.NT - 1;
   const int row = tile * 32 + j;
@@ -383,35 +381,54 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int af_launch_fwd(int net, int train, const FwdArgs* a, hipStream_t s) {
-  const dim3 grid((a->NT - a->tile0 + 3) / 4), block(256);
-  const size_t lds = 2 * AF_CHUNK_MAX;
-#define AF_FWD(NS)                                                                 \
-  do {                                                                             \
-    if (train) hipLaunchKernelGGL((k_mlp_fwd<NS, true>), grid, block, lds, s, *a); \
-    else       hipLaunchKernelGGL((k_mlp_fwd<NS, false>), grid, block, lds, s, *a);\
-  } while (0)
-  switch (net) {
-    case AF_NET_MAP1:  AF_FWD(NsMap1);  break;
-    case AF_NET_MAP2:  AF_FWD(NsMap2);  break;
-    case AF_NET_ATLAS: AF_FWD(NsAtlas); break;
-    case AF_NET_ALPHA: AF_FWD(NsAlpha); break;
-    default: return -1;
+// One launch, up to AF_MAX_NETS row-tile ranges of different nets back to back ("parts").  A workgroup finds
+// its part by its index and runs that net's chain.  Packing several nets (or the odd last round of one net
+// next to another net) into one grid removes the idle tail of separate launches: 2188 row tiles of the
+// 7-segment mapping batch are 2.14 rounds of the 1024 SIMDs but cost 3 as a launch of their own.
+// Parts of one launch must be independent of each other (the host orders dependent work across launches).
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi(MultiFwd m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0, base = 0;
+  const int wg = blockIdx.x;
+  while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
+  switch (m.net[s]) {
+    case AF_NET_MAP1:  mlp_fwd_body<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  mlp_fwd_body<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: mlp_fwd_body<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
+    default:           mlp_fwd_body<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
   }
-#undef AF_FWD
+}
+
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi(MultiBwd m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0, base = 0;
+  const int wg = blockIdx.x;
+  while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
+  switch (m.net[s]) {
+    case AF_NET_MAP1:  mlp_bwd_body<NsMap1>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  mlp_bwd_body<NsMap2>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: mlp_bwd_body<NsAtlas>(m.a[s], wg - base, smem); break;
+    default:           mlp_bwd_body<NsAlpha>(m.a[s], wg - base, smem); break;
+  }
+}
+
+// wg_end[] is filled here from the parts' tile ranges
+extern "C" int af_launch_fwd_multi(MultiFwd* m, int train, hipStream_t s) {
+  int tot = 0;
+  for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
+  if (tot <= 0) return 0;
+  const size_t lds = 2 * AF_CHUNK_MAX;
+  if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<true>), dim3(tot), dim3(256), lds, s, *m);
+  else       hipLaunchKernelGGL((k_mlp_fwd_multi<false>), dim3(tot), dim3(256), lds, s, *m);
   return (int)hipGetLastError();
 }
 
-extern "C" int af_launch_bwd(int net, const BwdArgs* a, hipStream_t s) {
-  const dim3 grid((a->NT - a->tile0 + 3) / 4), block(256);
-  const size_t lds = 2 * AF_CHUNK_MAX;
-  switch (net) {
-    case AF_NET_MAP1:  hipLaunchKernelGGL((k_mlp_bwd<NsMap1>),  grid, block, lds, s, *a); break;
-    case AF_NET_MAP2:  hipLaunchKernelGGL((k_mlp_bwd<NsMap2>),  grid, block, lds, s, *a); break;
-    case AF_NET_ATLAS: hipLaunchKernelGGL((k_mlp_bwd<NsAtlas>), grid, block, lds, s, *a); break;
-    case AF_NET_ALPHA: hipLaunchKernelGGL((k_mlp_bwd<NsAlpha>), grid, block, lds, s, *a); break;
-    default: return -1;
-  }
+extern "C" int af_launch_bwd_multi(MultiBwd* m, hipStream_t s) {
+  int tot = 0;
+  for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(k_mlp_bwd_multi, dim3(tot), dim3(256), 2 * AF_CHUNK_MAX, s, *m);
   return (int)hipGetLastError();
 }
 
@@ -432,14 +449,10 @@ extern "C" int af_mlp_chunk_bytes(int net, int which) {
   }
 }
 
-extern "C" int af_mlp_init() {   // opt in to 128 KB dynamic LDS for every instantiation
+extern "C" int af_mlp_init() {   // opt in to 128 KB dynamic LDS
   hipError_t e = hipSuccess;
 #define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AF_CHUNK_MAX); if (r != hipSuccess) e = r; } while (0)
-  AF_ATTR((k_mlp_fwd<NsMap1, true>));  AF_ATTR((k_mlp_fwd<NsMap1, false>));
-  AF_ATTR((k_mlp_fwd<NsMap2, true>));  AF_ATTR((k_mlp_fwd<NsMap2, false>));
-  AF_ATTR((k_mlp_fwd<NsAtlas, true>)); AF_ATTR((k_mlp_fwd<NsAtlas, false>));
-  AF_ATTR((k_mlp_fwd<NsAlpha, true>)); AF_ATTR((k_mlp_fwd<NsAlpha, false>));
-  AF_ATTR((k_mlp_bwd<NsMap1>)); AF_ATTR((k_mlp_bwd<NsMap2>)); AF_ATTR((k_mlp_bwd<NsAtlas>)); AF_ATTR((k_mlp_bwd<NsAlpha>));
+  AF_ATTR((k_mlp_fwd_multi<true>)); AF_ATTR((k_mlp_fwd_multi<false>)); AF_ATTR(k_mlp_bwd_multi);
 #undef AF_ATTR
   return (int)e;
 }

@@ -20,11 +20,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# algorithmic FLOPs per MLP row: forward, dX chain, dW
-FLOP_ROW = {
-    "fwd_map": 526848.0, "bwd_map": 525312.0, "dw_map": 526848.0,
-    "fwd_atlas": 829168.0, "bwd_atlas": 808448.0, "dw_atlas": 829168.0,
-}
 
 
 def synth_video_device(resx, resy, nframes, seed, device):
@@ -153,6 +148,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pretrain-iters", type=int, default=1)
+    ap.add_argument("--first-iter", type=int, default=-1, help="first timed iteration (default: K steps centred on the global-rigidity switch at 5000/5001)")
     args = ap.parse_args()
 
     import torch
@@ -182,8 +178,8 @@ def main():
 
     K, W = args.steps, args.warmup
     switch = cfg.stop_global_rigidity + 1                           # first iteration without the global term
-    first = max(0, switch - K // 2)
-    classes = ("prep", "fwd_map", "fwd_atlas", "loss", "bwd_atlas", "bwd_map", "dw", "adam")
+    first = max(0, switch - K // 2) if args.first_iter < 0 else args.first_iter
+    classes = af.TIMING_NAMES      # prep, fwd_1, fwd_2, loss, bwd_1, bwd_2, dw, adam (include/atlasfit.h: af_get_timing)
 
 
     # ---- warm-up (W untimed steps, all kernel classes timed to find the dominant one)
@@ -200,18 +196,10 @@ def main():
                       torch.cuda.synchronize, dist if world > 1 else None, dev)
     tk = af.timing(reset=True)
 
-    # ---- roofline of the dominant kernel: algorithmic FLOPs per launch / mean HIP-event duration
-    flops_launch = 0.0
-    for k in range(K):
-        (rm, ra, _, _), _ = af.step_work(first + k)
-        if dom in ("fwd_map", "bwd_map"):
-            flops_launch += rm * FLOP_ROW[dom]
-        elif dom in ("fwd_atlas", "bwd_atlas"):
-            flops_launch += ra * FLOP_ROW[dom]
-        elif dom == "dw":
-            flops_launch += rm * FLOP_ROW["dw_map"] + ra * FLOP_ROW["dw_atlas"]
-    flops_launch /= K
+    # ---- roofline of the dominant kernel: algorithmic FLOPs per launch (accumulated by the library from the rows each
+    # launch covered) / mean HIP-event duration over the timed region
     dom_ms = tk[dom][0] / max(tk[dom][1], 1)
+    flops_launch = tk[dom][2] / max(tk[dom][1], 1)
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K))
 
@@ -230,7 +218,8 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": dom_ms, "flops_per_launch": flops_launch,
                          "whole_step_tflops": total_flops / dt / 1e12, "whole_step_frac": total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes}},
+                         "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes},
+                         "warmup_tflops_by_kernel": {c: (tw[c][2] / tw[c][0] / 1e9 if tw[c][0] > 0 and tw[c][2] > 0 else None) for c in classes}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -112,11 +112,13 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);
-/* Time the most recent kernels: returns accumulated HIP-event milliseconds per kernel class since the last
- * reset: [0]=prep [1]=fwd_map1 [2]=fwd_atlas [3]=loss [4]=bwd_atlas [5]=bwd_map1 [6]=dw [7]=adam
- * [8]=fwd_map2 [9]=fwd_alpha [10]=bwd_map2 [11]=bwd_alpha; ms16[16], counts16[16]. */
-int af_set_timing(af_handle* h, int class_mask);   /* bit i enables HIP-event timing of kernel class i */
-int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, int reset);
+/* Time the most recent launches: accumulated HIP-event milliseconds, launch counts and algorithmic FLOPs per
+ * launch class since the last reset: [0]=prep [1]=fwd_1 [2]=fwd_2 [3]=loss [4]=bwd_1 [5]=bwd_2 [6]=dw [7]=adam.
+ * A step has two forward and two backward MLP launches: fwd_1 = the mapping batch's whole rounds (two_layer:
+ * alpha + both mappings), fwd_2 = atlas + the remainder; bwd_1 = atlas + remainder, bwd_2 = the rest.
+ * ms16[16], counts16[16], flops16[16] (any may be NULL). */
+int af_set_timing(af_handle* h, int class_mask);   /* bit i enables HIP-event timing of launch class i */
+int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset);
 /* Algorithmic work of ONE train step at the given iteration: MLP rows per net (indexed by af_net) and the
  * fwd+bwd FLOPs of the step. */
 int af_step_work(const af_handle* h, int iter, int64_t rows4[4], double* flops);

@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int which = 0; which < 4; ++which) {
     auto go = [&]() {
-      if (which == 0) af_launch_fwd(AF_NET_MAP1, 1, &fa, 0); else if (which == 1) af_launch_bwd(AF_NET_MAP1, &ba, 0);
+      if (which == 0) { MultiFwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = fa; af_launch_fwd_multi(&m, 1, 0); }
+      else if (which == 1) { MultiBwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = ba; af_launch_bwd_multi(&m, 0); }
       else if (which == 2) af_launch_fwd16(AF_NET_MAP1, 1, &fa, 0); else af_launch_bwd16(AF_NET_MAP1, &ba, 0);
     };
     for (int r = 0; r < 3; ++r) go();
