@@ -58,13 +58,32 @@ def synth_video_device(resx, resy, nframes, seed, device):
     return frames, flows, flows_rev, mask, mask_rev
 
 
-def init_state_dicts(seed):
-    """torch default nn.Linear init in the reference's construction order (stage1_neural_atlas.py:112-128)."""
+def synth_fg_mask_device(resx, resy, nframes, seed, device):
+    """Foreground mask of the two-layer workload: a soft-edged disc crossing the frame (fractional values, like the
+    bilinearly resized masks the reference feeds, unwrap_utils.py:68-70)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed + 1000)
+    cx0 = float(torch.rand(1, generator=g)) * 0.1 * resx + 0.3 * resx
+    cy0 = float(torch.rand(1, generator=g)) * 0.2 * resy + 0.4 * resy
+    r = 0.22 * min(resx, resy)
+    yy, xx = torch.meshgrid(torch.arange(resy, device=device, dtype=torch.float32),
+                            torch.arange(resx, device=device, dtype=torch.float32), indexing="ij")
+    m = torch.empty(resy, resx, nframes, device=device)
+    for f in range(nframes):
+        d = ((xx - (cx0 + 0.8 * f)) ** 2 + (yy - (cy0 - 0.3 * f)) ** 2).sqrt()
+        m[:, :, f] = ((r - d) / 2.0 + 0.5).clamp(0.0, 1.0)
+    return m
+
+
+def init_state_dicts(seed, two_layer=False):
+    """torch default nn.Linear init in the reference's construction order (stage1_neural_atlas.py:112-128;
+    stage1_neural_atlas_seg.py:127-161: mapping1, mapping2, atlas, alpha)."""
     import torch
     import aiod_amd
     torch.manual_seed(seed)
     sds = {}
-    for net in (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS):
+    nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_MAPPING2, aiod_amd.NET_ATLAS, aiod_amd.NET_ALPHA) if two_layer else (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS)
+    for net in nets:
         sd = {}
         for i, (o, k) in enumerate(aiod_amd.atlasfit.imlp_shapes(net)):
             lin = torch.nn.Linear(k, o)
@@ -74,18 +93,25 @@ def init_state_dicts(seed):
     return sds
 
 
-def cpu_baseline(resx, resy, nframes, seed, sds, video_dev, budget_s):
+def cpu_baseline(resx, resy, nframes, seed, sds, video_dev, budget_s, two_layer=False):
     """The oracle (a PyTorch-CPU restatement of the reference loop) on the host cores, same workload,
     bounded sample: iterations until ~budget_s seconds (>= 4), half with the global-rigidity term."""
     import torch
     import aiod_amd
     from oracle import atlas_oracle as O
     cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
-    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video_dev]
-    v = O.Video(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None])
-    m, a = O.build_single_atlas_models(cfg, seed=0)
-    m.load_state_dict(sds[aiod_amd.NET_MAPPING1]); a.load_state_dict(sds[aiod_amd.NET_ATLAS])
-    tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video_dev[:5]]
+    if two_layer:
+        v = O.SegVideo(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None], video_dev[5].cpu())
+        models = O.build_seg_models(cfg, seed=0)
+        for net, mdl in zip((aiod_amd.NET_MAPPING1, aiod_amd.NET_MAPPING2, aiod_amd.NET_ATLAS, aiod_amd.NET_ALPHA), models):
+            mdl.load_state_dict(sds[net])
+        tr = O.SegAtlasTrainer(cfg, v, models=models)
+    else:
+        v = O.Video(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None])
+        m, a = O.build_single_atlas_models(cfg, seed=0)
+        m.load_state_dict(sds[aiod_amd.NET_MAPPING1]); a.load_state_dict(sds[aiod_amd.NET_ATLAS])
+        tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
     N = cfg["samples_batch"]
     g = torch.Generator().manual_seed(seed)
     P = tr.jif_all.shape[1]
@@ -148,6 +174,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pretrain-iters", type=int, default=1)
+    ap.add_argument("--two-layer", action="store_true", help="BASELINE configs[4]: fg/bg dual-atlas path (stage1_neural_atlas_seg.py) instead of configs[1]")
     ap.add_argument("--first-iter", type=int, default=-1, help="first timed iteration (default: K steps centred on the global-rigidity switch at 5000/5001)")
     args = ap.parse_args()
 
@@ -165,16 +192,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
-    cfg = aiod_amd.default_config(args.resx, args.resy, args.frames)
+    cfg = aiod_amd.default_config(args.resx, args.resy, args.frames, two_layer=args.two_layer)
     N = cfg.samples_batch
     af = aiod_amd.AtlasFit(cfg, device=local)
-    video = synth_video_device(args.resx, args.resy, args.frames, seed=shard_for_rank(rank, world)[0], device=dev)
+    vseed = shard_for_rank(rank, world)[0]
+    video = synth_video_device(args.resx, args.resy, args.frames, seed=vseed, device=dev)
+    if args.two_layer:
+        video = video + (synth_fg_mask_device(args.resx, args.resy, args.frames, seed=vseed, device=dev),)
     af.upload_video(*video)
-    sds = init_state_dicts(1234 + rank)
-    af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1])
-    af.load_state_dict(aiod_amd.NET_ATLAS, sds[aiod_amd.NET_ATLAS])
-    if args.pretrain_iters > 0:
-        af.pre_train_mapping(args.pretrain_iters, seed=rank)     # untimed; puts the mapping in a realistic regime
+    sds = init_state_dicts(1234 + rank, args.two_layer)
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    if args.pretrain_iters > 0:                                  # untimed; puts the mapping(s) in a realistic regime
+        af.pre_train_mapping(args.pretrain_iters, seed=rank)
+        if args.two_layer:
+            af.pre_train_mapping(args.pretrain_iters, seed=rank + 100, net=aiod_amd.NET_MAPPING2)
 
     K, W = args.steps, args.warmup
     switch = cfg.stop_global_rigidity + 1                           # first iteration without the global term
@@ -210,9 +242,10 @@ def main():
             "metric": "atlas-fit sampled points/sec (stage1 main loop)", "value": value, "unit": "sampled points/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
-                                   "timed iterations %d..%d (half with the global-rigidity rows); one video per GPU"
-                                   % (args.frames, args.resx, args.resy, N, first, first + K - 1),
+            "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
+                                   "timed iterations %d..%d (global-rigidity rows while i <= 5000); one video per GPU"
+                                   % (4 if args.two_layer else 1, " (fg/bg dual atlas + alpha MLP)" if args.two_layer else "",
+                                      args.frames, args.resx, args.resy, N, first, first + K - 1),
                        "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -223,7 +256,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.resx, args.resy, args.frames, 0, sds, video, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args.resx, args.resy, args.frames, 0, sds, video, args.cpu_seconds, args.two_layer)
             except Exception as e:   # the baseline is a reported number, never the product
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
     af.close()
