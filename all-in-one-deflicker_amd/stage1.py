@@ -1,6 +1,8 @@
-"""Drop-in stage-1 entry point: same flags, config keys, on-disk inputs and results tree as the reference's
-`src/stage1_neural_atlas.py` (CLI :257-281, main :27-255), with the optimisation loop running in
-libatlasfit.so.  Host-side pieces restated here (numpy / PIL only — cv2, imageio, skimage, tensorboard are not
+"""Drop-in stage-1 entry points: same flags, config keys, on-disk inputs and results tree as the reference's
+`src/stage1_neural_atlas.py` (CLI :257-281, main :27-255) and, with `two_layer` (see stage1_seg.py), its fg/bg
+twin `src/stage1_neural_atlas_seg.py` (CLI :333-369, main :25-331; extra input `<vid>_seg/*.png` read by
+`load_input_data`, unwrap_utils.py:40-103; checkpoint with the four nets, evaluate.py:215-232), with the
+optimisation loop running in libatlasfit.so.  Host-side pieces restated here (numpy / PIL only — cv2, imageio, skimage, tensorboard are not
 required): the input builder `load_input_data_single` (src/models/stage_1/unwrap_utils.py:105-163 incl.
 `resize_flow` :33-38 and `compute_consistency` :10-23), and the parts of `evaluate_model_single`
 (src/models/stage_1/evaluate.py:605-793) that stage 2 and the metric consume: the checkpoint (:616-622), the
@@ -79,6 +81,25 @@ def compute_consistency(flow12, flow21):
     return (diff[:, :, 0] ** 2 + diff[:, :, 1] ** 2) ** 0.5
 
 
+def load_mask_frames(resy, resx, number_of_frames, vid_root, vid_name):
+    """The mask part of load_input_data (unwrap_utils.py:43,60,66-70): `<vid>_seg/*.{jpg,png}` / 255, resized with
+    cv2.resize(mask, (resx, resy), cv2.INTER_NEAREST) — the flag lands in the `dst` slot, so the resize is the
+    default BILINEAR one and the masks are fractional."""
+    from PIL import Image
+    seg_dir = Path(vid_root) / f"{vid_name}_seg"
+    files = sorted(list(seg_dir.glob("*.jpg")) + list(seg_dir.glob("*.png")))
+    if len(files) < number_of_frames:
+        raise FileNotFoundError("%d mask frames under %s, need %d: run the reference's src/preprocess_mask_*.py first "
+                                "(external segmentation models, out of scope of this library)" % (len(files), seg_dir, number_of_frames))
+    out = np.zeros((resy, resx, number_of_frames), np.float32)
+    for i in range(number_of_frames):
+        m = np.array(Image.open(str(files[i]))).astype(np.float64) / 255.0
+        if m.ndim == 3:
+            m = m[:, :, 0]
+        out[:, :, i] = resize_bilinear(m, resx, resy).astype(np.float32)
+    return out
+
+
 def load_input_data_single(resy, resx, maximum_number_of_frames, data_folder, filter_optical_flow, vid_root, vid_name):
     """unwrap_utils.py:105-163.  Returns numpy fp32 arrays in the reference's layouts:
     video_frames (resy,resx,3,F), optical_flows / _reverse (resy,resx,2,F,1), masks (resy,resx,F,1)."""
@@ -121,27 +142,34 @@ def load_input_data_single(resy, resx, maximum_number_of_frames, data_folder, fi
 
 
 # ---------------------------------------------------------------------------------------------
-# checkpoint format (evaluate.py:616-622; resume stage1_neural_atlas.py:141-146)
-def _torch_modules(sd_map, sd_atlas):
-    import torch
-    from .atlasfit import NET_ATLAS, NET_MAPPING1, imlp_shapes
+# checkpoint format (evaluate.py:616-622 / :215-232; resume stage1_neural_atlas.py:141-146 / _seg.py:180-187)
+def _ckpt_layout(two_layer):
+    """(checkpoint key, net) in the optimizer's param-group order (stage1_neural_atlas.py:132-134:
+    mapping, atlas; stage1_neural_atlas_seg.py:165-169: mapping1, mapping2, alpha, atlas)."""
+    from .atlasfit import NET_ALPHA, NET_ATLAS, NET_MAPPING1, NET_MAPPING2
+    if two_layer:
+        return [("model_F_mapping1_state_dict", NET_MAPPING1), ("model_F_mapping2_state_dict", NET_MAPPING2),
+                ("model_F_alpha_state_dict", NET_ALPHA), ("F_atlas_state_dict", NET_ATLAS)]
+    return [("model_F_mapping1_state_dict", NET_MAPPING1), ("F_atlas_state_dict", NET_ATLAS)]
 
-    def build(net, sd):
-        m = torch.nn.Module()
-        m.hidden = torch.nn.ModuleList([torch.nn.Linear(k, o) for (o, k) in imlp_shapes(net)])
-        m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
-        return m
-    return build(NET_MAPPING1, sd_map), build(NET_ATLAS, sd_atlas)
+
+def _torch_module(net, sd):
+    import torch
+    from .atlasfit import imlp_shapes
+    m = torch.nn.Module()
+    m.hidden = torch.nn.ModuleList([torch.nn.Linear(k, o) for (o, k) in imlp_shapes(net)])
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    return m
 
 
 def save_checkpoint(af, path, iteration):
-    """torch.save of the reference's dict: F_atlas_state_dict, iteration, model_F_mapping1_state_dict,
-    optimizer_all_state_dict (a genuine torch.optim.Adam state dict, param order mapping then atlas)."""
+    """torch.save of the reference's dict: the nets' state dicts, `iteration`, and `optimizer_all_state_dict`
+    (a genuine torch.optim.Adam state dict in the reference's param-group order)."""
     import torch
-    from .atlasfit import NET_ATLAS, NET_MAPPING1
-    mm, ma = _torch_modules(af.state_dict(NET_MAPPING1), af.state_dict(NET_ATLAS))
-    opt = torch.optim.Adam([{"params": list(mm.parameters())}, {"params": list(ma.parameters())}], lr=float(af.cfg.lr))
-    for net, mod in ((NET_MAPPING1, mm), (NET_ATLAS, ma)):
+    layout = _ckpt_layout(af.two_layer)
+    mods = [_torch_module(net, af.state_dict(net)) for _, net in layout]
+    opt = torch.optim.Adam([{"params": list(m.parameters())} for m in mods], lr=float(af.cfg.lr))
+    for (_, net), mod in zip(layout, mods):
         m, v, step = af.adam_state(net)
         off = 0
         for p in mod.parameters():
@@ -149,19 +177,22 @@ def save_checkpoint(af, path, iteration):
             opt.state[p] = {"step": torch.tensor(float(step)), "exp_avg": torch.from_numpy(m[off:off + n].reshape(p.shape).copy()),
                             "exp_avg_sq": torch.from_numpy(v[off:off + n].reshape(p.shape).copy())}
             off += n
-    torch.save({"F_atlas_state_dict": ma.state_dict(), "iteration": iteration,
-                "model_F_mapping1_state_dict": mm.state_dict(), "optimizer_all_state_dict": opt.state_dict()}, str(path))
+    ck = {key: mod.state_dict() for (key, _), mod in zip(layout, mods)}
+    ck["iteration"] = iteration
+    ck["optimizer_all_state_dict"] = opt.state_dict()
+    torch.save(ck, str(path))
 
 
 def load_checkpoint(af, path):
     import torch
-    from .atlasfit import NET_ATLAS, NET_MAPPING1, imlp_shapes
+    from .atlasfit import imlp_shapes
     ck = torch.load(str(path), map_location="cpu", weights_only=False)
-    af.load_state_dict(NET_MAPPING1, ck["model_F_mapping1_state_dict"])
-    af.load_state_dict(NET_ATLAS, ck["F_atlas_state_dict"])
+    layout = _ckpt_layout(af.two_layer)
+    for key, net in layout:
+        af.load_state_dict(net, ck[key])
     st = ck["optimizer_all_state_dict"]["state"]
     idx, step = 0, 0
-    for net in (NET_MAPPING1, NET_ATLAS):
+    for _, net in layout:
         ms, vs = [], []
         for (o, k) in imlp_shapes(net):
             for _ in range(2):               # weight, bias
@@ -181,6 +212,8 @@ def evaluate_model_single(af, video_frames, results_folder, iteration, save_chec
     eval_dir.mkdir(parents=True, exist_ok=True)
     if save_checkpoint_file:
         save_checkpoint(af, results_folder / "checkpoint", iteration)
+        if af.two_layer:                                   # evaluate.py:224-232 keeps a second copy per evaluation
+            save_checkpoint(af, eval_dir / "checkpoint", iteration)
     F = video_frames.shape[3]
     psnrs = np.zeros(F)
     for f in range(F):
@@ -192,8 +225,8 @@ def evaluate_model_single(af, video_frames, results_folder, iteration, save_chec
     return float(psnrs.mean())
 
 
-def main(config, args):
-    """stage1_neural_atlas.py:27-255 with the loop in libatlasfit.so."""
+def main(config, args, two_layer=False):
+    """stage1_neural_atlas.py:27-255 (two_layer: stage1_neural_atlas_seg.py:25-331) with the loop in libatlasfit.so."""
     from PIL import Image
     from . import atlasfit as A
     import glob
@@ -215,25 +248,28 @@ def main(config, args):
     flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
         resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
     F = video_frames.shape[3]
-    af = A.AtlasFit(A.default_config(resx, resy, F, config), device=getattr(args, "device_ordinal", 0))
-    af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask)
+    mask_frames = load_mask_frames(resy, resx, F, vid_root, vid_name) if two_layer else None
+    af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=getattr(args, "device_ordinal", 0))
+    af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask, mask_frames)
     import torch
     seed = getattr(args, "seed", None)
     if seed is not None:
         torch.manual_seed(seed)
     start_iteration = 0
     if not config["load_checkpoint"]:
-        sds = {}
-        for net in (A.NET_MAPPING1, A.NET_ATLAS):          # nn.Linear default init, reference construction order (:112-128)
+        # nn.Linear default init in the reference's construction order (:112-128; seg :127-161 mapping1, mapping2, atlas, alpha)
+        order = (A.NET_MAPPING1, A.NET_MAPPING2, A.NET_ATLAS, A.NET_ALPHA) if two_layer else (A.NET_MAPPING1, A.NET_ATLAS)
+        for net in order:
             sd = {}
             for i, (o, k) in enumerate(A.imlp_shapes(net)):
                 lin = torch.nn.Linear(k, o)
                 sd["hidden.%d.weight" % i] = lin.weight.detach(); sd["hidden.%d.bias" % i] = lin.bias.detach()
-            sds[net] = sd
-        af.load_state_dict(A.NET_MAPPING1, sds[A.NET_MAPPING1]); af.load_state_dict(A.NET_ATLAS, sds[A.NET_ATLAS])
+            af.load_state_dict(net, sd)
         if config["pretrain_mapping1"]:
             print("pre-training")
             af.pre_train_mapping(config["pretrain_iter_number"], seed=int(torch.randint(2 ** 31, (1,))))
+        if two_layer and config["pretrain_mapping2"]:
+            af.pre_train_mapping(config["pretrain_iter_number"], seed=int(torch.randint(2 ** 31, (1,))), net=A.NET_MAPPING2)
     else:
         start_iteration = load_checkpoint(af, config["checkpoint_path"])
     sampler_seed = int(torch.randint(2 ** 31, (1,)))
@@ -251,13 +287,15 @@ def main(config, args):
     return last_psnr
 
 
-def _cli(argv=None):
+def _cli(argv=None, two_layer=False):
     parser = argparse.ArgumentParser()
     parser.add_argument("--config", type=str, default="config_flow_100.json")
     parser.add_argument("--vid_name", type=str, default="Around_the_world_in_1896_001")
     parser.add_argument("--root", type=str, default="data/test/")
-    parser.add_argument("--down", type=int, default=4)
+    parser.add_argument("--down", type=int, default=1 if two_layer else 4)      # stage1_neural_atlas_seg.py:339 vs stage1_neural_atlas.py:262
     parser.add_argument("--gpu", type=int, default=0)
+    if two_layer:
+        parser.add_argument("--class_name", type=str, default="portrait", help="(reference flag; the mask preprocessors are external)")
     parser.add_argument("--seed", type=int, default=None, help="(extension) seed torch's RNG for reproducible runs")
     args = parser.parse_args(argv)
     os.environ["CUDA_VISIBLE_DEVICES"] = "%d" % args.gpu        # reference :267-268 (HIP honours it on ROCm)
@@ -272,7 +310,7 @@ def _cli(argv=None):
         from .atlasfit import REFERENCE_CONFIG
         print("config %s not found: using the shipped hyper-parameters" % cfg_path)
         config = dict(REFERENCE_CONFIG)
-    return main(config, args)
+    return main(config, args, two_layer)
 
 
 if __name__ == "__main__":

@@ -235,6 +235,20 @@ def main():
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K))
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of
+    # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
+    # quoted when it covers this kernel and workload, else null.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r1b_traffic.json")
+    kname = {"dw": "k_dw", "fwd_1": "k_mlp_fwd_multi<true>", "fwd_2": "k_mlp_fwd_multi<true>", "bwd_1": "k_mlp_bwd_multi", "bwd_2": "k_mlp_bwd_multi"}.get(dom)
+    if os.path.exists(tpath) and not args.two_layer and (args.resx, args.resy, args.frames) == (768, 432, 80) and args.first_iter < 0:
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj["kernels"][kname]["hbm_bytes"]
+            traffic_src = "profiles/r1b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
+        except Exception:
+            traffic = None
+
     out = None
     if rank == 0:
         value = world * N * K / dt
@@ -248,7 +262,7 @@ def main():
                                       args.frames, args.resx, args.resy, N, first, first + K - 1),
                        "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                          "kernel_ms": dom_ms, "flops_per_launch": flops_launch,
                          "whole_step_tflops": total_flops / dt / 1e12, "whole_step_frac": total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes},

@@ -85,3 +85,59 @@ def test_cli_results_tree_checkpoint_and_resume(tmp_path, small_video, golden, m
     assert it == 40 and af.adam_state(aiod_amd.NET_ATLAS)[2] == 41
     assert np.array_equal(af.state_dict(aiod_amd.NET_ATLAS)["hidden.3.weight"], ck["F_atlas_state_dict"]["hidden.3.weight"].numpy())
     af.close()
+
+
+def _write_masks(tmp, v, name):
+    from PIL import Image
+    d = tmp / (name + "_seg"); d.mkdir()
+    for f in range(v.F):
+        Image.fromarray(np.round(v.mask_frames[:, :, f].numpy() * 255).astype(np.uint8)).save(str(d / ("%05d.png" % f)))
+
+
+def test_mask_loader_reproduces_reference_tensor(tmp_path, small_seg_video):
+    import aiod_amd.stage1 as S
+    v = small_seg_video
+    _write_video(tmp_path, v)
+    _write_masks(tmp_path, v, "vid")
+    m = S.load_mask_frames(v.resy, v.resx, v.F, tmp_path, "vid")
+    assert m.shape == (v.resy, v.resx, v.F)
+    assert np.abs(m - np.round(v.mask_frames.numpy() * 255) / 255).max() < 1e-7
+    half = S.load_mask_frames(v.resy // 2, v.resx // 2, v.F, tmp_path, "vid")      # bilinear (fractional), not nearest
+    assert half.shape == (v.resy // 2, v.resx // 2, v.F) and ((half > 0.02) & (half < 0.98)).any()
+    with pytest.raises(FileNotFoundError):
+        S.load_mask_frames(v.resy, v.resx, v.F, tmp_path, "missing")
+
+
+@pytest.mark.gpu
+def test_two_layer_cli_results_tree_checkpoint_and_resume(tmp_path, small_seg_video, monkeypatch):
+    """stage1_neural_atlas_seg.py drop-in: four-net checkpoint in the reference's format, frames, PSNR, resume."""
+    import torch
+    import aiod_amd
+    import aiod_amd.stage1 as S
+    from oracle import atlas_oracle as O
+    v = small_seg_video
+    _write_video(tmp_path / "data", v, "clip")
+    _write_masks(tmp_path / "data", v, "clip")
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    cfg.update(samples_batch=256, iters_num=21, evaluate_every=20, pretrain_iter_number=2, stop_global_rigidity=10, stop_bootstrapping_iteration=15)
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    monkeypatch.chdir(tmp_path)
+    psnr = S._cli(["--config", str(tmp_path / "cfg.json"), "--vid_name", "clip", "--root", str(tmp_path / "data"), "--seed", "5"], two_layer=True)
+    res = tmp_path / "results" / "clip" / "stage_1"
+    assert (res / "checkpoint").exists() and (res / "000020" / "checkpoint").exists()       # evaluate.py:215-232 writes both
+    assert len(list((res / "output").glob("*.png"))) == v.F and len(list((res / "000020").glob("PSNR_*"))) == 1
+    ck = torch.load(res / "checkpoint", map_location="cpu", weights_only=False)
+    assert set(ck) == {"F_atlas_state_dict", "iteration", "model_F_mapping1_state_dict", "model_F_mapping2_state_dict",
+                       "model_F_alpha_state_dict", "optimizer_all_state_dict"} and ck["iteration"] == 20
+    m1, m2, at, al = O.build_seg_models(cfg, seed=0)
+    m1.load_state_dict(ck["model_F_mapping1_state_dict"]); m2.load_state_dict(ck["model_F_mapping2_state_dict"])
+    at.load_state_dict(ck["F_atlas_state_dict"]); al.load_state_dict(ck["model_F_alpha_state_dict"])
+    opt = torch.optim.Adam([{"params": list(m.parameters())} for m in (m1, m2, al, at)], lr=1e-4)      # reference group order
+    opt.load_state_dict(ck["optimizer_all_state_dict"])
+    assert int(opt.state_dict()["state"][0]["step"]) == 21
+    mean, _ = O.mean_psnr_seg(m1, m2, at, al, v)               # oracle render of the checkpointed weights vs the PNG-quantised input
+    assert abs(mean - psnr) < 0.1
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg, two_layer=True))
+    assert S.load_checkpoint(af, res / "checkpoint") == 20 and af.adam_state(aiod_amd.NET_ALPHA)[2] == 21
+    assert np.array_equal(af.state_dict(aiod_amd.NET_ALPHA)["hidden.0.weight"], ck["model_F_alpha_state_dict"]["hidden.0.weight"].numpy())
+    af.close()
