@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "af_create", "af_destroy", "af_last_error", "af_upload_video", "af_param_count", "af_set_params",
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
-    "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size",
+    "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records",
 ]
 
 
@@ -162,6 +162,7 @@ def load_library(path=None):
         "af_step_work": (i32, [vp, i32, C.POINTER(i64 * 4), C.POINTER(C.c_double)]),
         "af_loss_width": (i32, [vp]),
         "af_config_size": (sz, []),
+        "af_debug_records": (i32, [vp, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -339,6 +340,13 @@ class AtlasFit:
         assert rows.ndim == 2 and rows.shape[1] == 4
         out = np.empty_like(rows)
         self._chk(self.lib.af_debug_forward(self.h, net, _ptr(rows), rows.shape[0], _ptr(out)))
+        return out
+
+    def read_records(self, inds):
+        """(n, 16) packed pixel records for pixel-frame indices `inds` (column numbers of get_tuples' table)."""
+        inds = np.ascontiguousarray(inds, np.int64)
+        out = np.empty((inds.size, 16), np.float32)
+        self._chk(self.lib.af_debug_records(self.h, _ptr(inds), inds.size, _ptr(out)))
         return out
 
     def set_debug(self, on=True):

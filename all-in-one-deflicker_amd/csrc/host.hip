@@ -953,6 +953,18 @@ static int ensure_render(af_handle* h, int rows) {
   return 0;
 }
 
+int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out) {
+  if (!h || !inds || !out || n <= 0) return AF_EINVAL;
+  if (!h->have_video) return h->fail(AF_ESTATE, "af_debug_records: no video uploaded");
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  const int64_t P = (int64_t)h->cfg.resx * h->cfg.resy * h->cfg.number_of_frames;
+  for (int i = 0; i < n; ++i) {
+    if (inds[i] < 0 || inds[i] >= P) return h->fail(AF_EINVAL, "af_debug_records: index out of range");
+    HCHK(hipMemcpy(out + (size_t)i * AF_REC_F, h->table + (size_t)inds[i] * AF_REC_F, AF_REC_F * 4, hipMemcpyDeviceToHost));
+  }
+  return AF_OK;
+}
+
 int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* out) {
   if (!h || !in || !out || rows <= 0) return AF_EINVAL;
   if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");

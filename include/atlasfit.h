@@ -109,6 +109,9 @@ int af_sync(af_handle* h);
 /* ---- test / measurement hooks (not part of the reference surface) --------------------------------- */
 /* Run one net forward on caller rows: in [rows][4] host -> out [rows][4] host. */
 int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* out);
+/* Read back n 64-byte pixel records of the packed table: out [n][16] = rgb(3), d/dx rgb(3), d/dy rgb(3), fwd flow(2),
+ * bwd flow(2), fwd mask, bwd mask, fg mask, for pixel-frame indices inds[n] (the k of get_tuples' column k). */
+int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);

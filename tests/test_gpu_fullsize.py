@@ -152,3 +152,89 @@ def test_batch_without_valid_flow_reports_nan_like_reference():
         af.train_steps(0, 1, None, seed=0)
     assert e.value.code == -4
     af.close()
+
+
+# ---- BASELINE configs[2]: 200 frames (the reference's maximum_number_of_frames), table resident in HBM
+def _records_from_source(video, inds, resx, resy):
+    """What the 64-B record of pixel-frame index k must hold, gathered by torch from the reference-layout tensors."""
+    frames, flows, flows_rev, mask, mask_rev = video[:5]
+    k = torch.as_tensor(inds, device=frames.device)
+    P2 = resx * resy
+    f, rem = k // P2, k % P2
+    y, x = rem // resx, rem % resx
+    rgb = frames[y, x, :, f]
+    dx = torch.where((x + 1 < resx)[:, None], frames[y, (x + 1).clamp(max=resx - 1), :, f] - rgb, torch.zeros_like(rgb))
+    dy = torch.where((y + 1 < resy)[:, None], frames[(y + 1).clamp(max=resy - 1), x, :, f] - rgb, torch.zeros_like(rgb))
+    fg = video[5][y, x, f] if len(video) > 5 else torch.zeros_like(mask[y, x, f])
+    return torch.cat((rgb, dx, dy, flows[y, x, :, f], flows_rev[y, x, :, f], mask[y, x, f][:, None], mask_rev[y, x, f][:, None], fg[:, None]), dim=1).cpu().numpy()
+
+
+def test_200_frames_iteration_matches_oracle_and_table_is_exact():
+    """80 -> 200 frames at 768x432 (P = 66.4 M records, 4.25 GB table): the packed table equals the source tensors
+    bit for bit at random and at corner indices, and one loop iteration matches the CPU oracle."""
+    import aiod_amd
+    import bench
+    from oracle import atlas_oracle as O
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 200
+    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
+    af.upload_video(*video)
+    P = F * resx * resy
+    g = torch.Generator().manual_seed(9)
+    inds = torch.cat((torch.randint(P, (500,), generator=g), torch.tensor([0, resx - 1, resx * resy - 1, P - 1, P - resx, (F - 1) * resx * resy])))
+    assert np.array_equal(af.read_records(inds.numpy()), _records_from_source(video, inds, resx, resy))
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    sds = bench.init_state_dicts(77)
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video]
+    v = O.Video(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None])
+    m, a = O.build_single_atlas_models(cfg, seed=0)
+    m.load_state_dict(sds[aiod_amd.NET_MAPPING1]); a.load_state_dict(sds[aiod_amd.NET_ATLAS])
+    tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    binds = torch.randint(P, (cfg["samples_batch"],), generator=g)
+    ref = tr.loss_and_grads(6000, binds)
+    hip = af.train_steps(6000, 1, binds.numpy())[0]
+    want = np.array([ref[k] for k in ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")])
+    assert np.allclose(hip[:6], want, rtol=1e-3, atol=1e-9), (hip, want)
+    af.close()
+
+
+def test_200_frames_1080p_table_resident_in_hbm():
+    """The largest configuration BASELINE.json names (200 frames, full resolution 1920x1080): a 26.5 GB record table
+    (P = 414.7 M, byte offsets beyond 2^34) packed from ~16 GB of device-resident source tensors.  Size-independent
+    properties only: table == source at random / extreme indices, the loop is finite and bit-reproducible, the
+    valid-flow counters equal the masks at the sampled indices, and the two-layer record field (fg mask) is carried."""
+    import aiod_amd
+    import bench
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 1920, 1080, 200
+    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev)
+    video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=4, device=dev),)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
+    af.upload_video(*video)
+    P = F * resx * resy
+    assert P * 64 > 2 ** 34
+    g = torch.Generator().manual_seed(3)
+    inds = torch.cat((torch.randint(P, (800,), generator=g), torch.tensor([0, P - 1, P - resx * resy, resx * resy * 100 + 12345])))
+    assert np.array_equal(af.read_records(inds.numpy()), _records_from_source(video, inds, resx, resy))
+    sds = bench.init_state_dicts(5)
+    outs = []
+    N = af.N
+    binds = torch.randint(P, (3, N), generator=g)
+    for _ in range(2):
+        for net in af.nets:
+            af.load_state_dict(net, sds[net])
+        _zero_adam(af)
+        outs.append((af.train_steps(4999, 3, binds.numpy()), af.get_params_flat(aiod_amd.NET_MAPPING1)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.isfinite(outs[0][0]).all()
+    k = binds.to(dev)
+    P2 = resx * resy
+    f, rem = k // P2, k % P2
+    nf = (video[3][rem // resx, rem % resx, f] != 0).sum(dim=1).cpu().numpy()
+    nb = (video[4][rem // resx, rem % resx, f] != 0).sum(dim=1).cpu().numpy()
+    assert np.array_equal(outs[0][0][:, 6], nf) and np.array_equal(outs[0][0][:, 7], nb)
+    af.close()
+    del video
+    torch.cuda.empty_cache()
