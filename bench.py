@@ -203,8 +203,12 @@ def main():
     sds = init_state_dicts(1234 + rank, args.two_layer)
     for net in af.nets:
         af.load_state_dict(net, sds[net])
-    if args.pretrain_iters > 0:                                  # untimed; puts the mapping(s) in a realistic regime
+    pre_ms = None
+    if args.pretrain_iters > 0:                                  # outside the timed region; puts the mapping(s) in a realistic regime
+        af.pre_train_mapping(1, seed=rank + 7)                   # warm the code path, then time pre_train_mapping for the record
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         af.pre_train_mapping(args.pretrain_iters, seed=rank)
+        torch.cuda.synchronize(); pre_ms = (time.perf_counter() - t0) * 1e3 / (args.pretrain_iters * args.frames)
         if args.two_layer:
             af.pre_train_mapping(args.pretrain_iters, seed=rank + 100, net=aiod_amd.NET_MAPPING2)
 
@@ -224,16 +228,27 @@ def main():
     af.set_timing(1 << classes.index(dom))                         # events only around the dominant kernel
 
     # ---- timed region: EXACTLY K steps
-    dt = timed_region(lambda: af.train_steps(first, K, None, seed=rank, return_losses=False),
+    got = {}
+    dt = timed_region(lambda: got.update(losses=af.train_steps(first, K, None, seed=rank, return_losses=True)),
                       torch.cuda.synchronize, dist if world > 1 else None, dev)
     tk = af.timing(reset=True)
+    # Rows of the flow-match segments whose consistency mask is 0 are computed but masked out (static row counts, no
+    # compaction); the reference would not evaluate them (loss_utils.py:326-356).  The algorithmic
+    # FLOP counts below therefore charge only the measured valid fractions p_f, p_b.
+    L = got["losses"]
+    nv = L[:, -4:-2] if args.two_layer else L[:, 6:8]              # (#valid fwd, #valid bwd) per iteration
+    FWD = {"map1": 526848.0, "map2": 264704.0, "alpha": 802304.0}; DX = {"map1": 525312.0, "map2": 263168.0, "alpha": 786944.0}
+    inv = float((2 * N - nv.sum(axis=1)).sum())                     # invalid flow-match rows over the K steps, per net
+    nets_inv = ("map1", "map2", "alpha") if args.two_layer else ("map1",)
+    masked_step_flops = inv * sum(2 * FWD[n] + DX[n] for n in nets_inv)          # fwd + dW + dX of rows the reference skips
+    masked_dw_flops = inv * sum(FWD[n] for n in nets_inv)
 
     # ---- roofline of the dominant kernel: algorithmic FLOPs per launch (accumulated by the library from the rows each
     # launch covered) / mean HIP-event duration over the timed region
     dom_ms = tk[dom][0] / max(tk[dom][1], 1)
-    flops_launch = tk[dom][2] / max(tk[dom][1], 1)
+    flops_launch = (tk[dom][2] - (masked_dw_flops if dom == "dw" else 0.0)) / max(tk[dom][1], 1)
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    total_flops = sum(af.step_work(first + k)[1] for k in range(K))
+    total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of
     # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
@@ -261,9 +276,11 @@ def main():
                                    % (4 if args.two_layer else 1, " (fg/bg dual atlas + alpha MLP)" if args.two_layer else "",
                                       args.frames, args.resx, args.resy, N, first, first + K - 1),
                        "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
+            "pretrain_ms_per_step": pre_ms,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                          "kernel_ms": dom_ms, "flops_per_launch": flops_launch,
+                         "valid_flow_fraction": float(nv.sum() / (2.0 * N * K)),
                          "whole_step_tflops": total_flops / dt / 1e12, "whole_step_frac": total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes},
                          "warmup_tflops_by_kernel": {c: (tw[c][2] / tw[c][0] / 1e9 if tw[c][0] > 0 and tw[c][2] > 0 else None) for c in classes}},
