@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "af_create", "af_destroy", "af_last_error", "af_upload_video", "af_param_count", "af_set_params",
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
-    "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records",
+    "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
 ]
 
 
@@ -163,6 +163,7 @@ def load_library(path=None):
         "af_loss_width": (i32, [vp]),
         "af_config_size": (sz, []),
         "af_debug_records": (i32, [vp, vp, i32, vp]),
+        "af_debug_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32 * 3)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)

@@ -419,12 +419,17 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
 FwdArgs tile_range(FwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
 BwdArgs tile_range(BwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
 
-// The mapping batch splits into whole rounds of the chip (ncu workgroups x 4 row tiles) and a remainder.  The
-// whole rounds must contain every row the atlas chain depends on (the first `dep_rows` rows); if they do not,
-// the batch is not split.
-int whole_round_tiles(const af_handle* h, int NT, int dep_rows) {
-  const int round = h->ncu * 4, t1 = NT / round * round;
-  return t1 * 32 >= dep_rows ? t1 : NT;
+// The mapping batch splits into whole rounds of the chip (ncu workgroups x 4 row tiles), [0, T1), and a remainder
+// that rides with the atlas chain.  The whole rounds must contain every row the atlas chain depends on (the first
+// `dep_rows` rows); if they do not, the batch is not split (T1 = NT).  Workgroup i + ncu is dispatched behind
+// workgroup i (measured: two workgroups over one round cost a full atlas chain when they queue behind atlas
+// workgroups, nothing when they queue behind the shorter mapping ones), so the remainder's first E workgroups —
+// E = the number of workgroups beyond one round — lead the atlas launch: [T1, T2) before the atlas part, [T2, NT) after.
+void plan_mapping_split(int ncu, int NT_map, int NT_atlas, int dep_rows, int& T1, int& T2) {
+  const int round = ncu * 4, t1 = NT_map / round * round;
+  T1 = t1 * 32 >= dep_rows ? t1 : NT_map;
+  const int extra = (NT_atlas + 3) / 4 + (NT_map - T1 + 3) / 4 - ncu;
+  T2 = std::min(NT_map, T1 + 4 * std::max(0, extra));
 }
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
@@ -478,14 +483,10 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
   // Launch 1: the whole rounds of the mapping batch (they hold the 3N rows the atlas reads).  Launch 2: the atlas
   // chain plus the mapping remainder — rigidity / flow rows nothing in this launch depends on — in the CUs the
   // atlas workgroups leave idle.  The backward pass mirrors it (the remainder needs no atlas gradient).
-  int rc;
-  const int T1 = whole_round_tiles(h, NT_map, 3 * N);
+  int rc, T1, T2;
+  plan_mapping_split(h->ncu, NT_map, NT_atlas, 3 * N, T1, T2);
   const FwdArgs fm = fwd_args(h, M, M.coords, M.out_buf, NT_map, true);
   if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, tile_range(fm, 0, T1), nseg * N}}, true)) != 0) return rc;
-  // Workgroup i + ncu is dispatched behind workgroup i (measured: two workgroups over one round cost a full atlas
-  // chain when they queue behind atlas workgroups, nothing when they queue behind the shorter mapping ones), so the
-  // remainder's first E workgroups lead the grid, E = the number of workgroups beyond one round.
-  const int T2 = std::min(NT_map, T1 + 4 * std::max(0, (NT_atlas + 3) / 4 + (NT_map - T1 + 3) / 4 - h->ncu));
   if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_MAP1, tile_range(fm, T1, T2), nseg * N},
                                     {AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true), 3 * N},
                                     {AF_NET_MAP1, tile_range(fm, T2, NT_map), nseg * N}}, true)) != 0) return rc;
@@ -951,6 +952,14 @@ static int ensure_render(af_handle* h, int rows) {
   HCHK(dalloc(&h->r_rgb, rp * 3)); HCHK(dalloc(&h->r_sse, (rp + 255) / 256));
   h->render_rows_cap = rows;
   return 0;
+}
+
+int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[3]) {
+  if (!out3 || ncu <= 0) return AF_EINVAL;
+  const int NT_map = tiles_of(rows_map), NT_atlas = tiles_of(rows_atlas);
+  plan_mapping_split(ncu, NT_map, NT_atlas, dep_rows, out3[0], out3[1]);
+  out3[2] = NT_map;
+  return AF_OK;
 }
 
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out) {

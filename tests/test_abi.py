@@ -53,3 +53,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("CPU oracle", ""), os.path.join(dp, f)
+
+
+def test_launch_plan_arithmetic(lib):
+    """The packed-launch split of the mapping batch (host.hip plan_mapping_split) for a 256-CU chip."""
+    import ctypes
+
+    def plan(ncu, rows_map, rows_atlas, dep):
+        out = (ctypes.c_int * 3)()
+        assert lib.af_debug_plan(ncu, rows_map, rows_atlas, dep, ctypes.byref(out)) == 0
+        return tuple(out)
+    N = 10000
+    # 7 segments: 2188 tiles = 2 whole rounds (2048) + 35 workgroups; atlas 235 WGs -> 14 beyond one round lead the grid
+    assert plan(256, 7 * N, 3 * N, 3 * N) == (2048, 2048 + 4 * 14, 2188)
+    # 9 segments: 2813 tiles = 2 whole rounds + 192 workgroups (171 beyond one round)
+    assert plan(256, 9 * N, 3 * N, 3 * N) == (2048, 2048 + 4 * 171, 2813)
+    # small batches (tests, pre-train): no whole round holds the rows the atlas depends on -> no split, nothing rides along
+    assert plan(256, 9 * 256, 3 * 256, 3 * 256) == (72, 72, 72)
+    # the whole rounds must cover the dependent rows: 1024 tiles hold 32768 rows < 3N = 36000 -> unsplit
+    assert plan(256, 5 * 12000 // 4, 36000, 36000)[0] == plan(256, 5 * 12000 // 4, 36000, 36000)[2]
+    # remainder fits beside the atlas workgroups in one round: nothing needs to lead
+    t1, t2, nt = plan(256, 7 * 9700, 3 * 9700, 3 * 9700)
+    assert (t1, t2, nt) == (2048, 2048, 2122)
