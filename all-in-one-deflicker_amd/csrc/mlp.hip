@@ -118,12 +118,23 @@ struct ChunkStream {
 // max(z, 0) as ONE v_max_f32 (the C-level fmaxf adds a canonicalising v_max in front)
 AF_DEV float af_relu(float z) { float v; asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(z)); return v; }
 
-AF_DEV void init_bias(f32x16 (&acc)[8], __amdgpu_buffer_rsrc_t rb, int layer, int h) {
+// Accumulator initialisation = bias.  The net's padded bias rows ([NL][256] floats, <= 8 KB) are copied once per
+// workgroup into LDS behind the two weight buffers: 32 ds_read_b128 per layer cost a fraction of the 32 VMEM loads
+// they replace (each VMEM instruction steals ~40 cycles of MFMA issue from the only wave of its SIMD).
+#define AF_BIAS_LDS (2 * AF_CHUNK_MAX)          // byte offset of the bias rows in dynamic LDS
+#define AF_LDS_BYTES (2 * AF_CHUNK_MAX + AF_MAX_LAYERS * AF_HID * 4)
+template <int NL> AF_DEV void stage_bias(const float* bias, char* smem, int tid) {
+  float* dst = (float*)(smem + AF_BIAS_LDS);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) dst[i * AF_HID + tid] = bias[i * AF_HID + tid];     // 256 threads x NL rows; visible after the first barrier
+}
+AF_DEV void init_bias(f32x16 (&acc)[8], const char* smem, int layer, int h) {
+  const char* b = smem + AF_BIAS_LDS + (layer * AF_HID + 4 * h) * 4;
 #pragma unroll
   for (int T = 0; T < 8; ++T) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = af_bl128(rb, h * 16, (layer * AF_HID + 32 * T + 8 * q) * 4);
+      const f32x4 b4 = *(const f32x4*)(b + (32 * T + 8 * q) * 4);
       acc[T][q * 4 + 0] = b4[0]; acc[T][q * 4 + 1] = b4[1]; acc[T][q * 4 + 2] = b4[2]; acc[T][q * 4 + 3] = b4[3];
     }
   }
@@ -160,7 +171,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
 
-  const auto rb = af_rsrc(a.bias, NS::NL * AF_HID * 4);
+  stage_bias<NS::NL>(a.bias, smem, tid);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
   float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
   {
@@ -241,16 +252,16 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   };
 
   // ---- layer 0
-  init_bias(acc, rb, 0, h);
   {
-    const char* buf = cs.next<CB::L0>();
+    const char* buf = cs.next<CB::L0>();            // its barrier also publishes the bias rows
+    init_bias(acc, smem, 0, h);
     mm_block<8, NS::K0G, 0, 4>(acc, pe, buf + a_off8, hook_dma);
   }
   relu_out(0);
 
   // ---- hidden layers 1 .. NL-2
   for (int l = 1; l <= NS::NL - 2; ++l) {
-    init_bias(acc, rb, l, h);
+    init_bias(acc, smem, l, h);
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
@@ -266,7 +277,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
     f32x16 acc1[1];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = af_bl128(rb, h * 16, ((NS::NL - 1) * AF_HID + 8 * q) * 4);
+      const f32x4 b4 = *(const f32x4*)(smem + AF_BIAS_LDS + ((NS::NL - 1) * AF_HID + 8 * q + 4 * h) * 4);
       acc1[0][q * 4 + 0] = b4[0]; acc1[0][q * 4 + 1] = b4[1]; acc1[0][q * 4 + 2] = b4[2]; acc1[0][q * 4 + 3] = b4[3];
     }
     const char* buf = cs.next<CB::LAST>();
@@ -418,7 +429,7 @@ extern "C" int af_launch_fwd_multi(MultiFwd* m, int train, hipStream_t s) {
   int tot = 0;
   for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
   if (tot <= 0) return 0;
-  const size_t lds = 2 * AF_CHUNK_MAX;
+  const size_t lds = AF_LDS_BYTES;
   if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<true>), dim3(tot), dim3(256), lds, s, *m);
   else       hipLaunchKernelGGL((k_mlp_fwd_multi<false>), dim3(tot), dim3(256), lds, s, *m);
   return (int)hipGetLastError();
@@ -428,7 +439,7 @@ extern "C" int af_launch_bwd_multi(MultiBwd* m, hipStream_t s) {
   int tot = 0;
   for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
   if (tot <= 0) return 0;
-  hipLaunchKernelGGL(k_mlp_bwd_multi, dim3(tot), dim3(256), 2 * AF_CHUNK_MAX, s, *m);
+  hipLaunchKernelGGL(k_mlp_bwd_multi, dim3(tot), dim3(256), AF_LDS_BYTES, s, *m);
   return (int)hipGetLastError();
 }
 
@@ -451,7 +462,7 @@ extern "C" int af_mlp_chunk_bytes(int net, int which) {
 
 extern "C" int af_mlp_init() {   // opt in to 128 KB dynamic LDS
   hipError_t e = hipSuccess;
-#define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AF_CHUNK_MAX); if (r != hipSuccess) e = r; } while (0)
+#define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES); if (r != hipSuccess) e = r; } while (0)
   AF_ATTR((k_mlp_fwd_multi<true>)); AF_ATTR((k_mlp_fwd_multi<false>)); AF_ATTR(k_mlp_bwd_multi);
 #undef AF_ATTR
   return (int)e;
