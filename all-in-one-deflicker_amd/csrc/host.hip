@@ -244,7 +244,7 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   const double seg_cost = 60.0;
   double work = 0;
   for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
-  int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (16.0 * 276.0)));
+  int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (4.0 * 276.0)));     // at least ~4 full-size row tiles per workgroup
   // Cut the job sequence (largest jobs first) into nwg pieces of equal cost.  Boundaries are placed on the
   // CUMULATIVE cost line (rounding to the nearest tile), so rounding never accumulates onto the last workgroup.
   std::vector<int> order(nj);

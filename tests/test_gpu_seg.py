@@ -179,3 +179,41 @@ def test_two_layer_handle_requires_mask(golden_seg, small_seg_video):
         h.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
     assert e.value.code == -1
     h.close()
+
+
+@pytest.mark.parametrize("two_layer", [False, True])
+def test_ragged_sizes_match_oracle(golden_seg, two_layer):
+    """samples_batch not a multiple of the 32-row tile / 128-row workgroup, odd frame size, portrait aspect
+    (resy > resx: the gradient rows normalise by resx, everything else by larger_dim = resy)."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    cfg = dict(golden_seg["config"]); cfg.update(samples_batch=250, stop_global_rigidity=5)
+    v = O.synthetic_seg_video(21, 37, 5, seed=11)
+    if two_layer:
+        models = O.build_seg_models(cfg, seed=3)
+        nets = _nets()
+        tr = O.SegAtlasTrainer(cfg, v, models=models)
+        names = O.SEG_TERMS
+    else:
+        models = O.build_single_atlas_models(cfg, seed=3)
+        nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS)
+        tr = O.SingleAtlasTrainer(cfg, v, mapping=models[0], atlas=models[1])
+        names = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+    h = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg, two_layer=two_layer))
+    h.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask,
+                   v.mask_frames if two_layer else None)
+    for net, m in zip(nets, models):
+        h.load_state_dict(net, m.state_dict())
+    g = torch.Generator().manual_seed(4)
+    h.set_debug(True)
+    for it in (2, 9):                                  # with and without the global-rigidity rows
+        inds = torch.randint(v.F * v.resx * v.resy, (250,), generator=g)
+        for net, m in zip(nets, models):               # same state on both sides before every comparison
+            h.load_state_dict(net, m.state_dict())
+        ref = tr.loss_and_grads(it, inds)
+        got = h.train_steps(it, 1, inds.numpy())[0]
+        assert np.allclose(got[:len(names)], [ref[k] for k in names], rtol=1e-3, atol=1e-6), (it, got, ref)
+        for net, m in zip(nets, models):
+            gh, gr = h.last_grads(net), O.flat_grads(m)
+            assert np.linalg.norm(gh - gr) < 2e-3 * np.linalg.norm(gr), (it, net)
+    h.close()
