@@ -142,7 +142,7 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
   size_t foff = 0;   // bytes relative to f_base
   for (int l = 0; l < n.NL; ++l) {
     const bool last = l == n.NL - 1;
-    const int mpad = last ? 32 : AF_HID;
+    const int mpad = last ? 4 : AF_HID;            // the output layer runs on 4x4x1 MFMA blocks (mlp.hip)
     const int groups = (l == 0) ? (n.in_kind == AF_IN_XYT ? 1 : peg) : (32 + (((n.skip >> l) & 1) ? peg : 0));
     n.f_mpad[l] = mpad; n.f_groups[l] = groups;
     n.f_off[l] = n.f_base + foff / 4;

@@ -32,7 +32,7 @@ template <class NS> struct ChunkBytes {
   static constexpr int L0   = af_round4k(NS::K0G * 2 * AF_HID * 16);                                            // forward layer 0
   static constexpr int HID  = 8 * 2 * AF_HID * 16;                                                            // a quarter of a 256x256 layer = 64 KB
   static constexpr int SKIP = af_round4k(NS::PEG * 2 * AF_HID * 16);                                            // PE columns of a skip layer
-  static constexpr int LAST = af_round4k((32 + (((NS::SKIP >> (NS::NL - 1)) & 1) ? NS::PEG : 0)) * 2 * 32 * 16);   // forward output layer (Mpad 32)
+  static constexpr int LAST = af_round4k((32 + (((NS::SKIP >> (NS::NL - 1)) & 1) ? NS::PEG : 0)) * 2 * 4 * 16);    // forward output layer (Mpad 4)
   static constexpr int BLAST = 2 * AF_HID * 16;                                                               // backward output layer: one k-group
   static constexpr int BL0  = 32 * 2 * 64 * 16;                                                               // backward layer 0 (Mpad 64 PE slots)
 };
@@ -272,26 +272,44 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
     relu_out(l);
   }
 
-  // ---- output layer (one 32-wide tile, OUT real rows), tanh
+  // ---- output layer (1..3 real outputs), tanh.  A 32-wide MFMA tile would spend 128+ full-rate MFMAs on 2 or 3
+  // useful rows (3 % of the whole chain); v_mfma_f32_4x4x1_16B_f32 does the same dot products in 4-output blocks:
+  // lane l = block (l >> 2) = (k-half h, row quad), column l & 3 = row within the quad, so the B operand is the
+  // activation register as it stands (lane = row, register = feature 8g+4h+p) and the A operand is W[l & 3][8g+4h+p]
+  // — the usual packed image with Mpad = 4.  Each k-half accumulates its own partial; one cross-half shuffle adds them.
   {
-    f32x16 acc1[1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = *(const f32x4*)(smem + AF_BIAS_LDS + ((NS::NL - 1) * AF_HID + 8 * q + 4 * h) * 4);
-      acc1[0][q * 4 + 0] = b4[0]; acc1[0][q * 4 + 1] = b4[1]; acc1[0][q * 4 + 2] = b4[2]; acc1[0][q * 4 + 3] = b4[3];
-    }
     const char* buf = cs.next<CB::LAST>();
-    const char* al = buf + (h * 32 + j) * 16;
-    mm_block<1, 32, 0, 4>(acc1, in, al, hook_dma_store);
-    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) mm_block<1, NS::PEG, 0, 4>(acc1, pe, al + 32 * 2 * 32 * 16, hook_dma);
-    if (live && h == 0) {
-      f32x4 o;
-      o[0] = tanhf(acc1[0][0]);
-      o[1] = NS::OUT > 1 ? tanhf(acc1[0][1]) : 0.f;
-      o[2] = NS::OUT > 2 ? tanhf(acc1[0][2]) : 0.f;
-      o[3] = 0.f;
-      *(f32x4*)(a.out + (size_t)row * 4) = o;
+    if constexpr (TRAIN) {     // the last hidden layer's activation tile (after the barrier: its wait must not cover them)
+      ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
+      ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
     }
+    const char* al = buf + (h * 4 + (lane & 3)) * 16;
+    f32x4 o4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o4[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const f32x4 w = *(const f32x4*)(al + g * 2 * 4 * 16);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], in[4 * g + p], o4[p], 0, 0, 0);
+    }
+    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) {
+#pragma unroll
+      for (int g = 0; g < NS::PEG; ++g) {
+        const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+      }
+    }
+    const f32x4 bias = *(const f32x4*)(smem + AF_BIAS_LDS + (NS::NL - 1) * AF_HID * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float z = (o4[0][i] + o4[1][i]) + (o4[2][i] + o4[3][i]);
+      z += __shfl_xor(z, 32);
+      o[i] = i < NS::OUT ? tanhf(z + bias[i]) : 0.f;
+    }
+    if (live && h == 0) *(f32x4*)(a.out + (size_t)row * 4) = o;
   }
 }
 
