@@ -254,13 +254,13 @@ def main():
     # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
     # quoted when it covers this kernel and workload, else null.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r1b_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r1c_traffic.json")
     kname = {"dw": "k_dw", "fwd_1": "k_mlp_fwd_multi<true>", "fwd_2": "k_mlp_fwd_multi<true>", "bwd_1": "k_mlp_bwd_multi", "bwd_2": "k_mlp_bwd_multi"}.get(dom)
     if os.path.exists(tpath) and not args.two_layer and (args.resx, args.resy, args.frames) == (768, 432, 80) and args.first_iter < 0:
         try:
             tj = json.load(open(tpath))
             traffic = tj["kernels"][kname]["hbm_bytes"]
-            traffic_src = "profiles/r1b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
+            traffic_src = "profiles/r1c_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
         except Exception:
             traffic = None
 
