@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
+    "af_resize_bilinear", "af_flow_consistency",
 ]
 
 
@@ -164,6 +165,8 @@ def load_library(path=None):
         "af_config_size": (sz, []),
         "af_debug_records": (i32, [vp, vp, i32, vp]),
         "af_debug_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32 * 3)]),
+        "af_resize_bilinear": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i64, C.c_double, C.c_double, i32]),
+        "af_flow_consistency": (i32, [i32, vp, vp, i32, i32, vp, i64, i64, C.c_float, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -216,6 +219,38 @@ def unflatten_state_dict(flat, net):
         out["hidden.%d.bias" % i] = flat[off:off + o].copy(); off += o
     assert off == flat.size
     return out
+
+
+# ---- input builder on the device (unwrap_utils.py:10-38,105-163) ------------------------------------------------
+def _util_chk(rc):
+    if rc != 0:
+        raise AtlasFitError(rc, load_library().af_last_error(None).decode())
+
+
+def resize_bilinear_device(src, dst, dh, dw, pix_stride, ch_stride, offset, scale=(1.0, 1.0), device=0):
+    """cv2.resize(src, (dw, dh)) (INTER_LINEAR) on the GPU.  src: torch CUDA tensor (H, W, C), uint8 or float32,
+    contiguous.  dst: torch CUDA float32 tensor; element (y, x, c) is written at
+    dst.view(-1)[(y*dw + x)*pix_stride + c*ch_stride + offset] (so a frame can land directly in (resy,resx,C,F))."""
+    import torch
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.float32
+    assert src.dtype in (torch.uint8, torch.float32) and src.dim() == 3
+    torch.cuda.synchronize()
+    sh, sw, ch = src.shape
+    _util_chk(load_library().af_resize_bilinear(int(device), C.c_void_p(src.data_ptr()), int(src.dtype == torch.uint8), sh, sw, ch,
+                                                C.c_void_p(dst.data_ptr()), int(dh), int(dw), int(pix_stride), int(ch_stride), int(offset),
+                                                float(scale[0]), float(scale[1]), 1))
+
+
+def flow_consistency_device(flow12, flow21, out, pix_stride, offset, thresh=1.0, device=0):
+    """unwrap_utils.py:10-23,151-159: out.view(-1)[(y*w + x)*pix_stride + offset] = (|| f12 + remap(f21, f12) || < thresh)
+    as 1.0 / 0.0 (thresh <= 0: the norm itself).  flow12 / flow21: torch CUDA float32 (h, w, 2) contiguous."""
+    import torch
+    assert flow12.is_cuda and flow21.is_cuda and out.is_cuda and flow12.is_contiguous() and flow21.is_contiguous() and out.is_contiguous()
+    assert flow12.dtype == torch.float32 and flow12.shape == flow21.shape and flow12.shape[2] == 2
+    torch.cuda.synchronize()
+    h, w, _ = flow12.shape
+    _util_chk(load_library().af_flow_consistency(int(device), C.c_void_p(flow12.data_ptr()), C.c_void_p(flow21.data_ptr()), h, w,
+                                                 C.c_void_p(out.data_ptr()), int(pix_stride), int(offset), float(thresh), 1))
 
 
 class AtlasFit:

@@ -13,6 +13,22 @@ struct PackArgs {
   int resx, resy, F;
 };
 
+// Input builder (load_input_data*, unwrap_utils.py:40-163): bilinear resize with cv2.resize's INTER_LINEAR geometry
+// (half-pixel centres, edge clamp, no anti-aliasing; :35,131) from an HWC source into an arbitrarily strided
+// destination, and the forward/backward flow-consistency field || f12 + remap(f21, f12) || (:10-23).
+struct ResizeArgs {
+  const void* src; int src_u8;        // HWC contiguous, float32 or uint8 (uint8 is divided by 255 first, :128)
+  int sh, sw, ch;
+  float* dst; int dh, dw;
+  long long pix_stride, ch_stride, offset;   // dst index = (y*dw + x)*pix_stride + c*ch_stride + offset
+  double scale0, scale1;              // per-channel multipliers of channels 0 / 1 (resize_flow, :36-37); 1 for images
+};
+struct ConsistencyArgs {
+  const float* f12; const float* f21; int h, w;     // (h, w, 2) each
+  float* out; long long pix_stride, offset;         // out[(y*w + x)*pix_stride + offset] = norm (thresh <= 0) or norm < thresh
+  float thresh;
+};
+
 struct PrepArgs {
   const float* table;
   const int64_t* inds;    // [N] pixel-frame indices of this iteration, or null -> device Philox

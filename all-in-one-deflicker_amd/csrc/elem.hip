@@ -59,6 +59,61 @@ __global__ void k_pack_table(PackArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Input builder kernels (one thread per destination pixel; fp64 interpolation like the numpy/cv2 double path).
+__global__ void k_resize_bilinear(ResizeArgs a) {
+#pragma clang fp contract(off)      // same roundings as the host restatement (no FMA contraction)
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)a.dh * a.dw) return;
+  const int y = (int)(idx / a.dw), x = (int)(idx - (long long)y * a.dw);
+  const double sx = (double)a.sw / a.dw, sy = (double)a.sh / a.dh;
+  const double fx = ((double)x + 0.5) * sx - 0.5, fy = ((double)y + 0.5) * sy - 0.5;
+  const double x0f = floor(fx), y0f = floor(fy);
+  const double ax = fx - x0f, ay = fy - y0f;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int x0c = min(max(x0, 0), a.sw - 1), x1c = min(max(x0 + 1, 0), a.sw - 1);
+  const int y0c = min(max(y0, 0), a.sh - 1), y1c = min(max(y0 + 1, 0), a.sh - 1);
+  for (int c = 0; c < a.ch; ++c) {
+    auto tap = [&](int yy, int xx) -> double {
+      const size_t i = ((size_t)yy * a.sw + xx) * a.ch + c;
+      return a.src_u8 ? (double)((const unsigned char*)a.src)[i] / 255.0 : (double)((const float*)a.src)[i];
+    };
+    const bool same = a.sh == a.dh && a.sw == a.dw;        // identity: the reference copies (no interpolation round-off)
+    double v;
+    if (same) v = tap(y, x);
+    else {
+      const double top = tap(y0c, x0c) * (1.0 - ax) + tap(y0c, x1c) * ax;
+      const double bot = tap(y1c, x0c) * (1.0 - ax) + tap(y1c, x1c) * ax;
+      v = top * (1.0 - ay) + bot * ay;
+    }
+    float o = (float)v;
+    if (c == 0) o = o * (float)a.scale0; else if (c == 1) o = o * (float)a.scale1;     // fp32, like `flow[:, :, c] *= s`
+    a.dst[idx * a.pix_stride + (long long)c * a.ch_stride + a.offset] = o;
+  }
+}
+
+__global__ void k_flow_consistency(ConsistencyArgs a) {
+#pragma clang fp contract(off)
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)a.h * a.w) return;
+  const int y = (int)(idx / a.w), x = (int)(idx - (long long)y * a.w);
+  const float u = a.f12[idx * 2], v = a.f12[idx * 2 + 1];
+  const float mx = u + (float)x, my = v + (float)y;                      // sampling position in the other frame
+  const float x0f = floorf(mx), y0f = floorf(my);
+  const long long x0 = (long long)x0f, y0 = (long long)y0f;
+  const float fx = mx - x0f, fy = my - y0f;
+  float acc[2];
+  for (int c = 0; c < 2; ++c) {
+    auto tap = [&](long long yy, long long xx) -> float {              // constant-0 border (cv2.remap default)
+      return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? a.f21[(yy * a.w + xx) * 2 + c] : 0.f;
+    };
+    acc[c] = tap(y0, x0) * (1.f - fx) * (1.f - fy) + tap(y0, x0 + 1) * fx * (1.f - fy) + tap(y0 + 1, x0) * (1.f - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy;
+  }
+  const float du = u + acc[0], dv = v + acc[1];
+  const float nrm = sqrtf(du * du + dv * dv);
+  a.out[idx * a.pix_stride + a.offset] = a.thresh > 0.f ? (nrm < a.thresh ? 1.f : 0.f) : nrm;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch preparation (stage1_neural_atlas.py:159-171; loss_utils.py:137-151, 230-233, 326-351).
 // Row segments of the mapping batch: 0 centre, 1 (x,y+1), 2 (x+1,y), 3 (x,y-d), 4 (x-d,y), 5 fwd-flow match,
 // 6 bwd-flow match, 7 (x,y-D), 8 (x-D,y); segments 7,8 exist only while the global rigidity term is on.
@@ -547,6 +602,16 @@ __global__ __launch_bounds__(256) void k_frame_finish_seg(const float* out_atlas
 
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+int af_launch_resize(const ResizeArgs* a, hipStream_t s) {
+  const long long n = (long long)a->dh * a->dw;
+  hipLaunchKernelGGL(k_resize_bilinear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
+int af_launch_consistency(const ConsistencyArgs* a, hipStream_t s) {
+  const long long n = (long long)a->h * a->w;
+  hipLaunchKernelGGL(k_flow_consistency, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);
+  return (int)hipGetLastError();
+}
 int af_launch_loss_seg(const LossSegArgs* a, hipStream_t s) {
   hipLaunchKernelGGL(k_loss_seg, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
   return (int)hipGetLastError();

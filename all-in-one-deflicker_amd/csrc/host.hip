@@ -27,6 +27,8 @@ int af_launch_pack(const PackArgs* a, hipStream_t s);
 int af_launch_prep(const PrepArgs* a, hipStream_t s);
 int af_launch_loss_single(const LossArgs* a, hipStream_t s);
 int af_launch_loss_seg(const LossSegArgs* a, hipStream_t s);
+int af_launch_resize(const ResizeArgs* a, hipStream_t s);
+int af_launch_consistency(const ConsistencyArgs* a, hipStream_t s);
 int af_launch_frame_finish_seg(const float* out_atlas, const float* out_alpha, size_t row2, const float* table, float* rgb_out, double* sse_part,
                                int npix, size_t rec0, hipStream_t s);
 int af_launch_pre_prep(const PrePrepArgs* a, hipStream_t s);
@@ -584,6 +586,53 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
 extern "C" {
 
 size_t af_config_size(void) { return sizeof(af_config); }
+
+// ---- input builder utilities (stateless; default stream of the device)
+namespace {
+struct Staged {   // host buffer mirrored on the device for the duration of a call
+  void* d = nullptr; bool own = false;
+  hipError_t in(const void* p, size_t bytes, bool on_device) {
+    if (on_device) { d = const_cast<void*>(p); return hipSuccess; }
+    hipError_t e = hipMalloc(&d, std::max<size_t>(bytes, 1)); if (e != hipSuccess) return e;
+    own = true;
+    return p ? hipMemcpy(d, p, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  }
+  ~Staged() { if (own) (void)hipFree(d); }
+};
+int util_fail(const char* what, hipError_t e) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); return AF_EHIP; }
+}  // namespace
+
+int af_resize_bilinear(int device_ordinal, const void* src, int src_u8, int sh, int sw, int ch, float* dst, int dh, int dw,
+                       int64_t pix_stride, int64_t ch_stride, int64_t offset, double scale0, double scale1, int on_device) {
+  if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || ch <= 0 || pix_stride <= 0) { g_create_error = "af_resize_bilinear: arguments"; return AF_EINVAL; }
+  hipError_t e = hipSetDevice(device_ordinal); if (e != hipSuccess) return util_fail("hipSetDevice", e);
+  if (!on_device && (pix_stride != ch || ch_stride != 1 || offset != 0)) { g_create_error = "af_resize_bilinear: host destinations must be HWC contiguous"; return AF_EINVAL; }
+  Staged s, d;
+  const size_t sbytes = (size_t)sh * sw * ch * (src_u8 ? 1 : 4), dbytes = (size_t)dh * dw * ch * 4;
+  if ((e = s.in(src, sbytes, on_device)) != hipSuccess) return util_fail("stage source", e);
+  if ((e = d.in(on_device ? (const void*)dst : nullptr, dbytes, on_device)) != hipSuccess) return util_fail("stage destination", e);
+  ResizeArgs a{s.d, src_u8, sh, sw, ch, (float*)d.d, dh, dw, pix_stride, ch_stride, offset, scale0, scale1};
+  int r = af_launch_resize(&a, nullptr); if (r) return util_fail("k_resize_bilinear", (hipError_t)r);
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return util_fail("k_resize_bilinear", e);
+  if (!on_device && (e = hipMemcpy(dst, d.d, dbytes, hipMemcpyDeviceToHost)) != hipSuccess) return util_fail("copy back", e);
+  return AF_OK;
+}
+
+int af_flow_consistency(int device_ordinal, const float* f12, const float* f21, int h, int w, float* out,
+                        int64_t pix_stride, int64_t offset, float thresh, int on_device) {
+  if (!f12 || !f21 || !out || h <= 0 || w <= 0 || pix_stride <= 0) { g_create_error = "af_flow_consistency: arguments"; return AF_EINVAL; }
+  hipError_t e = hipSetDevice(device_ordinal); if (e != hipSuccess) return util_fail("hipSetDevice", e);
+  if (!on_device && (pix_stride != 1 || offset != 0)) { g_create_error = "af_flow_consistency: host destinations must be contiguous"; return AF_EINVAL; }
+  Staged a12, a21, o;
+  const size_t fb = (size_t)h * w * 8, ob = (size_t)h * w * 4;
+  if ((e = a12.in(f12, fb, on_device)) != hipSuccess || (e = a21.in(f21, fb, on_device)) != hipSuccess) return util_fail("stage flows", e);
+  if ((e = o.in(on_device ? (const void*)out : nullptr, ob, on_device)) != hipSuccess) return util_fail("stage output", e);
+  ConsistencyArgs a{(const float*)a12.d, (const float*)a21.d, h, w, (float*)o.d, pix_stride, offset, thresh};
+  int r = af_launch_consistency(&a, nullptr); if (r) return util_fail("k_flow_consistency", (hipError_t)r);
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return util_fail("k_flow_consistency", e);
+  if (!on_device && (e = hipMemcpy(out, o.d, ob, hipMemcpyDeviceToHost)) != hipSuccess) return util_fail("copy back", e);
+  return AF_OK;
+}
 
 const char* af_last_error(const af_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -141,6 +141,80 @@ def load_input_data_single(resy, resx, maximum_number_of_frames, data_folder, fi
     return optical_flows_mask, video_frames, optical_flows_reverse_mask, optical_flows_reverse, optical_flows
 
 
+def load_input_data_device(resy, resx, maximum_number_of_frames, data_folder, filter_optical_flow, vid_root, vid_name,
+                           with_masks=False, device=0):
+    """load_input_data_single / load_input_data (unwrap_utils.py:40-163) with the per-pixel work on the GPU: files
+    are decoded on the host (PIL / np.load) and uploaded as they are; the bilinear resizes, the flow rescaling and the
+    forward/backward consistency masks run in libatlasfit.so (af_resize_bilinear, af_flow_consistency) and write
+    straight into the reference-layout tensors in HBM, which af_upload_video then packs without a host round trip.
+    Same arithmetic as the host functions above (fp64 interpolation, fp32 consistency); ~50 s of numpy work for an
+    80-frame 4x-downsampled clip become file decoding only.  Returns torch CUDA tensors:
+    (optical_flows_mask, video_frames, optical_flows_reverse_mask, optical_flows_reverse, optical_flows[, mask_frames])."""
+    import torch
+    from PIL import Image
+    from .atlasfit import flow_consistency_device, resize_bilinear_device
+    dev = torch.device("cuda", device)
+    data_folder, vid_root = Path(data_folder), Path(vid_root)
+    out_flow_dir = vid_root / f"{vid_name}_flow"
+    input_files = sorted(list(data_folder.glob("*.jpg")) + list(data_folder.glob("*.png")))
+    if not input_files:
+        raise FileNotFoundError("no *.jpg / *.png frames under %s" % data_folder)
+    F = int(np.minimum(maximum_number_of_frames, len(input_files)))
+    video_frames = torch.zeros((resy, resx, 3, F), device=dev)
+    optical_flows = torch.zeros((resy, resx, 2, F), device=dev)
+    optical_flows_reverse = torch.zeros((resy, resx, 2, F), device=dev)
+    optical_flows_mask = torch.zeros((resy, resx, F), device=dev)
+    optical_flows_reverse_mask = torch.zeros((resy, resx, F), device=dev)
+    mask_frames = torch.zeros((resy, resx, F), device=dev) if with_masks else None
+    mask_files = []
+    if with_masks:
+        seg_dir = vid_root / f"{vid_name}_seg"
+        mask_files = sorted(list(seg_dir.glob("*.jpg")) + list(seg_dir.glob("*.png")))
+        if len(mask_files) < F:
+            raise FileNotFoundError("%d mask frames under %s, need %d" % (len(mask_files), seg_dir, F))
+
+    def u8(path, channels):
+        im = np.array(Image.open(str(path)))
+        if im.dtype != np.uint8:
+            raise ValueError("%s: only 8-bit images are handled on the device path" % path)
+        if channels == 3:
+            im = np.tile(im[:, :, None], [1, 1, 3]) if im.ndim == 2 else im[:, :, :3]
+        else:
+            im = im[:, :, None] if im.ndim == 2 else im[:, :, :1]
+        return torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+
+    for i in range(F):
+        resize_bilinear_device(u8(input_files[i], 3), video_frames, resy, resx, 3 * F, F, i, device=device)
+        if with_masks:
+            resize_bilinear_device(u8(mask_files[i], 1), mask_frames, resy, resx, F, 0, i, device=device)
+
+    def flow(path):
+        f = torch.from_numpy(np.ascontiguousarray(np.load(path).astype(np.float32))).to(dev)
+        if f.shape[0] != resy or f.shape[1] != resx:
+            oldh, oldw = f.shape[0], f.shape[1]
+            r = torch.empty((resy, resx, 2), device=dev)
+            resize_bilinear_device(f, r, resy, resx, 2, 1, 0, scale=(resy / oldh, resx / oldw), device=device)   # resize_flow, :33-38
+            f = r
+        return f
+
+    for i in range(F - 1):
+        fn1, fn2 = input_files[i].name, input_files[i + 1].name
+        f12p, f21p = out_flow_dir / f"{fn1}_{fn2}.npy", out_flow_dir / f"{fn2}_{fn1}.npy"
+        if not f12p.exists() or not f21p.exists():
+            raise FileNotFoundError("optical flow %s missing: run the reference's src/preprocess_optical_flow.py first" % f12p)
+        f12, f21 = flow(f12p), flow(f21p)
+        optical_flows[:, :, :, i] = f12
+        optical_flows_reverse[:, :, :, i + 1] = f21
+        if filter_optical_flow:
+            flow_consistency_device(f12, f21, optical_flows_mask, F, i, 1.0, device=device)
+            flow_consistency_device(f21, f12, optical_flows_reverse_mask, F, i + 1, 1.0, device=device)
+        else:
+            optical_flows_mask[:, :, i] = 1.0
+            optical_flows_reverse_mask[:, :, i + 1] = 1.0
+    out = (optical_flows_mask, video_frames, optical_flows_reverse_mask, optical_flows_reverse, optical_flows)
+    return out + (mask_frames,) if with_masks else out
+
+
 # ---------------------------------------------------------------------------------------------
 # checkpoint format (evaluate.py:616-622 / :215-232; resume stage1_neural_atlas.py:141-146 / _seg.py:180-187)
 def _ckpt_layout(two_layer):
@@ -245,10 +319,16 @@ def main(config, args, two_layer=False):
     results_folder.mkdir(parents=True, exist_ok=True)
     with open(results_folder / "config.json", "w") as f:
         json.dump(config, f, indent=4)
-    flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
-        resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
+    if getattr(args, "host_loader", False):      # the numpy restatement of the reference loader (slow; kept as the cross-check)
+        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
+            resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
+        mask_frames = load_mask_frames(resy, resx, video_frames.shape[3], vid_root, vid_name) if two_layer else None
+    else:
+        t = load_input_data_device(resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name,
+                                   with_masks=two_layer, device=getattr(args, "device_ordinal", 0))
+        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
+        mask_frames = t[5] if two_layer else None
     F = video_frames.shape[3]
-    mask_frames = load_mask_frames(resy, resx, F, vid_root, vid_name) if two_layer else None
     af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=getattr(args, "device_ordinal", 0))
     af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask, mask_frames)
     import torch
@@ -297,6 +377,7 @@ def _cli(argv=None, two_layer=False):
     if two_layer:
         parser.add_argument("--class_name", type=str, default="portrait", help="(reference flag; the mask preprocessors are external)")
     parser.add_argument("--seed", type=int, default=None, help="(extension) seed torch's RNG for reproducible runs")
+    parser.add_argument("--host_loader", action="store_true", help="(extension) build the input tensors with the numpy loader instead of the device one")
     args = parser.parse_args(argv)
     os.environ["CUDA_VISIBLE_DEVICES"] = "%d" % args.gpu        # reference :267-268 (HIP honours it on ROCm)
     os.environ.setdefault("HIP_VISIBLE_DEVICES", "%d" % args.gpu)

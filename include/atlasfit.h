@@ -69,6 +69,21 @@ const char* af_last_error(const af_handle* h);   /* h may be NULL: message of th
 int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, const float* flow_bwd,
                     const float* mask_fwd, const float* mask_bwd, const float* mask_fg, int on_device);
 
+/* ---- input builder (the device side of load_input_data / load_input_data_single, unwrap_utils.py:40-163) ----------
+ * Stateless utilities on `device_ordinal`; with on_device != 0 the pointers are device pointers, else host buffers.
+ *
+ * af_resize_bilinear: cv2.resize(src, (dw, dh)) with the default INTER_LINEAR geometry (half-pixel centres, edge clamp,
+ * no anti-aliasing; unwrap_utils.py:35,131).  src is HWC contiguous, float32 (src_u8 = 0) or uint8 (src_u8 = 1: divided
+ * by 255 first, :128).  dst element (y, x, c) is written at dst[(y*dw + x)*pix_stride + c*ch_stride + offset] — e.g.
+ * frame f of video_frames (resy,resx,3,F): pix_stride 3F, ch_stride F, offset f.  scale0/scale1 multiply channels 0/1
+ * (resize_flow's newh/oldh and neww/oldw, :36-37); pass 1 for images.
+ * af_flow_consistency: out[(y*w + x)*pix_stride + offset] = || f12 + remap(f21, f12) ||_2 (:10-23, bilinear, zero
+ * border) if thresh <= 0, else 1.0 / 0.0 for norm < thresh (the mask of :151-159 with thresh = 1). */
+int af_resize_bilinear(int device_ordinal, const void* src, int src_u8, int sh, int sw, int ch, float* dst, int dh, int dw,
+                       int64_t pix_stride, int64_t ch_stride, int64_t offset, double scale0, double scale1, int on_device);
+int af_flow_consistency(int device_ordinal, const float* f12, const float* f21, int h, int w, float* out,
+                        int64_t pix_stride, int64_t offset, float thresh, int on_device);
+
 /* IMLP.state_dict() order: hidden.0.weight (out,in) row-major, hidden.0.bias, hidden.1.weight, ...
  * (src/models/stage_1/implicit_neural_networks.py:37-52). */
 size_t af_param_count(const af_handle* h, int net);

@@ -141,3 +141,41 @@ def test_two_layer_cli_results_tree_checkpoint_and_resume(tmp_path, small_seg_vi
     assert S.load_checkpoint(af, res / "checkpoint") == 20 and af.adam_state(aiod_amd.NET_ALPHA)[2] == 21
     assert np.array_equal(af.state_dict(aiod_amd.NET_ALPHA)["hidden.0.weight"], ck["model_F_alpha_state_dict"]["hidden.0.weight"].numpy())
     af.close()
+
+
+@pytest.mark.gpu
+def test_device_input_builder_matches_host_restatement(tmp_path, small_seg_video):
+    """af_resize_bilinear / af_flow_consistency (the device side of load_input_data, unwrap_utils.py:40-163) against the
+    numpy restatement: frames and masks stored at twice the working resolution (so the bilinear resize runs), flows
+    stored at another resolution (resize_flow's rescaling) and perturbed so that the consistency mask is non-trivial."""
+    import torch
+    import aiod_amd.stage1 as S
+    from PIL import Image
+    v = small_seg_video
+    rng = np.random.default_rng(2)
+    d = tmp_path / "clip"; d.mkdir(); fd = tmp_path / "clip_flow"; fd.mkdir(); sd = tmp_path / "clip_seg"; sd.mkdir()
+    H2, W2 = 2 * v.resy, 2 * v.resx
+    names = ["%05d.png" % f for f in range(v.F)]
+    for f in range(v.F):
+        Image.fromarray(rng.integers(0, 256, (H2, W2, 3), dtype=np.uint8)).save(str(d / names[f]))
+        Image.fromarray(rng.integers(0, 256, (H2, W2), dtype=np.uint8)).save(str(sd / names[f]))
+    fh, fw = v.resy + 8, v.resx + 16                                  # RAFT's padded resolution differs from the frames'
+    for f in range(v.F - 1):
+        f12 = (rng.standard_normal((fh, fw, 2)) * 1.5).astype(np.float32)
+        f21 = (-f12 + rng.standard_normal((fh, fw, 2)) * 0.6).astype(np.float32)
+        np.save(fd / ("%s_%s.npy" % (names[f], names[f + 1])), f12); np.save(fd / ("%s_%s.npy" % (names[f + 1], names[f])), f21)
+    hm, hf, hmr, hfr, hfl = S.load_input_data_single(v.resy, v.resx, 200, d, True, tmp_path, "clip")
+    hmask = S.load_mask_frames(v.resy, v.resx, v.F, tmp_path, "clip")
+    dm, df, dmr, dfr, dfl, dmask = [t.cpu().numpy() for t in S.load_input_data_device(v.resy, v.resx, 200, d, True, tmp_path, "clip", with_masks=True)]
+    assert np.abs(df - hf).max() < 1e-6 and np.abs(dmask - hmask).max() < 1e-6
+    assert np.abs(dfl - hfl[..., 0]).max() < 1e-5 and np.abs(dfr - hfr[..., 0]).max() < 1e-5
+    for a, b in ((dm, hm[..., 0]), (dmr, hmr[..., 0])):
+        assert 0.02 < b.mean() < 0.98                                     # a non-trivial mask
+        assert (a != b).mean() < 1e-3                                     # only pixels whose norm sits on the threshold may flip
+    # the norm field itself, on the host-resized flows
+    f12 = torch.from_numpy(np.ascontiguousarray(hfl[:, :, :, 0, 0])).cuda(); f21 = torch.from_numpy(np.ascontiguousarray(hfr[:, :, :, 1, 0])).cuda()
+    out = torch.empty(v.resy, v.resx, device="cuda")
+    aiod = __import__("aiod_amd")
+    aiod.atlasfit.flow_consistency_device(f12, f21, out, 1, 0, thresh=0.0)
+    ref = S.compute_consistency(hfl[:, :, :, 0, 0], hfr[:, :, :, 1, 0])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
