@@ -56,3 +56,36 @@ def test_sharding_covers_all_videos_once():
     for world in (1, 2, 4, 8):
         seen = sorted(v for r in range(world) for v in bench.shard_for_rank(r, world, 8))
         assert seen == list(range(8))
+
+
+def _launcher_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import aiod_amd  # noqa: F401
+    from aiod_amd import launch_videos as L
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    seen = []
+
+    def fake_stage1(name):            # stands in for stage1.main (needs a GPU): records what this rank was given
+        seen.append(name); time.sleep(0.05 * (rank + 1)); return 20.0 + len(name)
+    out = L.run(["--vid_names", "a", "bb", "ccc", "dddd", "eeeee"], backend="gloo", stage1_main=fake_stage1)
+    q.put((rank, seen, out))
+
+
+def test_multi_video_launcher_shards_and_gathers():
+    """launch_videos.py: five videos over two ranks (gloo, CPU): every video runs exactly once on its shard's rank,
+    the job time is the MAX over ranks, rank 0 reports all results."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_launcher_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, seen0, out0), (_, seen1, out1) = res
+    assert seen0 == ["a", "ccc", "eeeee"] and seen1 == ["bb", "dddd"]
+    assert out1 is None and out0["videos"] == 5 and out0["n_gpus"] == 2
+    assert out0["psnr"] == {"a": 21.0, "bb": 22.0, "ccc": 23.0, "dddd": 24.0, "eeeee": 25.0}
+    assert out0["wall_s"] >= 0.19                    # rank 1: two videos at 0.1 s each

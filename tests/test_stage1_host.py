@@ -179,3 +179,37 @@ def test_device_input_builder_matches_host_restatement(tmp_path, small_seg_video
     aiod.atlasfit.flow_consistency_device(f12, f21, out, 1, 0, thresh=0.0)
     ref = S.compute_consistency(hfl[:, :, :, 0, 0], hfr[:, :, :, 1, 0])
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_multi_video_launcher_single_rank(tmp_path, small_video, monkeypatch):
+    """launch_videos.py with one rank: two clips through stage1.main on GPU 0, results tree per clip, one JSON summary."""
+    import aiod_amd
+    from aiod_amd import launch_videos as L
+    (tmp_path / "data").mkdir()
+    for name in ("clipA", "clipB"):
+        _write_video_into(tmp_path / "data", small_video, name)
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    cfg.update(samples_batch=256, iters_num=11, evaluate_every=10, pretrain_iter_number=1, stop_global_rigidity=5)
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    out = L.run(["--vid_names", "clipA", "clipB", "--config", str(tmp_path / "cfg.json"), "--root", str(tmp_path / "data"), "--down", "1", "--seed", "3"])
+    assert out["videos"] == 2 and out["n_gpus"] == 1 and set(out["psnr"]) == {"clipA", "clipB"}
+    assert abs(out["psnr"]["clipA"] - out["psnr"]["clipB"]) < 1e-9          # same clip, same seed -> same result
+    for name in ("clipA", "clipB"):
+        assert len(list((tmp_path / "results" / name / "stage_1" / "output").glob("*.png"))) == small_video.F
+
+
+def _write_video_into(root, v, name):
+    from PIL import Image
+    d = root / name; d.mkdir(); fd = root / (name + "_flow"); fd.mkdir()
+    names = []
+    for f in range(v.F):
+        fn = "%05d.png" % f; names.append(fn)
+        Image.fromarray(np.round(v.video_frames[:, :, :, f].numpy() * 255).astype(np.uint8)).save(str(d / fn))
+    for f in range(v.F - 1):
+        np.save(fd / ("%s_%s.npy" % (names[f], names[f + 1])), v.optical_flows[:, :, :, f, 0].numpy())
+        np.save(fd / ("%s_%s.npy" % (names[f + 1], names[f])), v.optical_flows_reverse[:, :, :, f + 1, 0].numpy())
+    return d
