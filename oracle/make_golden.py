@@ -142,6 +142,24 @@ def main():
     assert np.allclose(end_map, O.flat_params(om), atol=2e-6) and np.allclose(end_atlas, O.flat_params(oa), atol=2e-6)
     ref_psnr, _ = O.mean_psnr(rm, ra, video)
 
+    # ---- 5. portrait aspect (resy > resx): the gradient loss normalises by resx while everything else uses
+    # larger_dim = resy (stage1_neural_atlas.py:186-188) — one iteration with and without the global term
+    pv = O.synthetic_video(24, 40, 5, seed=VSEED + 1)
+    prm, pra = ref_models(WSEED + 7)
+    pom, poa = O.build_single_atlas_models(c, seed=WSEED + 7)
+    ptr = O.SingleAtlasTrainer(c, pv, mapping=pom, atlas=poa)
+    pj = get_tuples(5, pv.video_frames)
+    assert torch.equal(pj, O.get_tuples(5, 40, 24))
+    pg = torch.Generator().manual_seed(5)
+    portrait = []
+    for it in (0, K_ITERS + 1):
+        pinds = torch.randint(pj.shape[1], (N,), generator=pg)
+        _, terms = ref_iteration(it, pj[:, pinds.view(-1, 1)], pv, prm, pra, c)
+        o_terms = ptr.loss_and_grads(it, pinds)
+        ora_t = np.array([o_terms[k] for k in ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")])
+        assert np.allclose(np.array(terms), ora_t, rtol=2e-5, atol=1e-7), (it, terms, ora_t)
+        portrait.append(terms)
+
     if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
         print("restatement == reference modules (check only, fixtures untouched)")
         return

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp16_fwd(FwdArgs a) {
         pe[g * 4 + 2] = ok ? cosf(p0) : 0.f; pe[g * 4 + 3] = ok ? cosf(p1) : 0.f;
       }
       if constexpr (TRAIN) {
-        const auto r = af_rsrc(a.pe_tile + (size_t)tile * 64 * 32, live ? 64 * 32 * 4 : 0);
+        const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, live ? 64 * 32 * 4 : 0);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp16_fwd(FwdArgs a) {
       }
     if constexpr (TRAIN) {
       if (live) *(uint2*)(a.masks + (((size_t)l * a.nt_stride * 2 + t16) * 64 + lane) * 2) = make_uint2(mk[0], mk[1]);
-      ts.r = af_rsrc(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+      ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) cs.issue2(); };
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp16_bwd(BwdArgs a) {
       for (int r = 0; r < 4; ++r)
         in[T * 4 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
                                                   (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 3], (T & 7) * 4 + r, 1));
-    ts.r = af_rsrc(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) cs.issue2(); };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 4) cs.issue2(); ts.template part<decltype(gi)::value>(in); };
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp16_bwd(BwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 4; ++T) { f32x4v z = {0.f, 0.f, 0.f, 0.f}; acc2[T] = z; }
     { const char* buf = cs.next(); mm16<4, 64, 16, 0, 4>(acc2, in, buf + (q * 64 + j) * 16, hook_dma_store); }
-    const auto r = af_rsrc(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+    const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
     float dx0 = 0.f, dx1 = 0.f;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
