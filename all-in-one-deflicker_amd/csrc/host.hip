@@ -20,6 +20,9 @@ extern "C" {
 int af_launch_fwd_multi(MultiFwd* m, int train, hipStream_t s);
 int af_launch_bwd_multi(MultiBwd* m, hipStream_t s);
 int af_mlp_init();
+int af_launch_fwd16(int net, const FwdArgs* a, hipStream_t s);
+int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s);
+int af_mlp16_init();
 int af_mlp_chunk_bytes(int net, int which);
 int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s);
 int af_dw_init();
@@ -667,7 +670,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
   h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_dw_init());
+  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init());
 
   describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
   describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
@@ -894,10 +897,14 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       p.half_main = half_main; p.t = (float)((double)f / (F / 2.0) - 1.0);
       p.coords = M.coords; p.x0_tile = M.x0_tile;
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
-      if ((rc = launch_fwd(h, T_FWD_1, {{net, fwd_args(h, M, M.coords, M.out_buf, NT, true), NB}}, true)) != 0) break;
+      // 16-row chains (mlp16.hip): the batch is smaller than one round of the chip, so a step is bound by the latency
+      // of one tile chain — half the rows per wave, half the latency
+      { Timer t(h, T_FWD_1, (double)NB * kFlopFwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true);
+        if (af_launch_fwd16(net, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      if ((rc = launch_bwd(h, T_BWD_2, {{net, bwd_args(h, M, NT), NB}})) != 0) break;
+      { Timer t(h, T_BWD_2, (double)NB * kFlopDx[net]); const BwdArgs ba = bwd_args(h, M, NT);
+        if (af_launch_bwd16(net, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
       rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * kFlopFwd[net]);
     }
   hipError_t e = hipStreamSynchronize(h->stream);
