@@ -39,11 +39,10 @@ enum { REC_RGB = 0, REC_DX = 3, REC_DY = 6, REC_FF = 9, REC_FB = 11, REC_MF = 13
 // dW job shapes: (out tiles, in tiles) of the layer block; per-wave split in dw.hip
 enum { DW_8x8 = 0, DW_8x2 = 1, DW_8x1 = 2, DW_1x8 = 3, DW_1x2 = 4 };
 
-struct AfChunk { uint32_t off; uint32_t bytes; };   // byte offset into the image buffer, multiple of 4096 bytes
+struct AfChunk { uint32_t off; uint32_t bytes; };   // host-side plan entry: byte offset into a net's image, size (multiple of 4096)
 
 struct FwdArgs {
-  const float* wimg;          // forward packed image (all layers of this net)
-  const AfChunk* chunks;      // chunk table for this net (forward order)
+  const float* wimg;          // forward packed image (all layers of this net, contiguous in stream order)
   const float* bias;          // [NL][256] padded biases
   const float* in;            // [rows_pad][4]  xyt coords, or uv (PE nets use .x,.y[,.z])
   const float* in1;           // rows >= split_row read in1[row - split_row] (second mapping net of the fg/bg path)
@@ -56,12 +55,10 @@ struct FwdArgs {
   int tile0;                  // first row tile of this launch
   int NT;                     // one past the last row tile of this launch
   int nt_stride;              // row tiles per layer plane of acts / masks (the whole batch)
-  int nchunks;
 };
 
 struct BwdArgs {
   const float* wimg;          // backward packed image (W^T per layer)
-  const AfChunk* chunks;      // chunk table (backward order)
   const float* out;           // [rows_pad][4] tanh outputs (forward)
   const float* dout;          // [rows_pad][4] dL/d out
   const uint32_t* masks;
@@ -75,7 +72,6 @@ struct BwdArgs {
   int tile0;
   int NT;
   int nt_stride;
-  int nchunks;
 };
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip

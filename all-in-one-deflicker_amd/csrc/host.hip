@@ -55,8 +55,7 @@ struct NetDesc {
   size_t f_off[AF_MAX_LAYERS]; int f_mpad[AF_MAX_LAYERS], f_groups[AF_MAX_LAYERS];
   long long b_off_img[AF_MAX_LAYERS]; int b_mpad[AF_MAX_LAYERS];
   size_t f_base = 0, b_base = 0, bias_base = 0;        // float offsets of this net's region (chunk offsets are relative to these)
-  std::vector<AfChunk> fchunks, bchunks;
-  AfChunk *d_fchunks = nullptr, *d_bchunks = nullptr;
+  std::vector<AfChunk> fchunks, bchunks;               // the planned chunk sequences (checked against the kernels' ChunkBytes)
   // activations
   int nt_cap = 0;
   float *coords = nullptr, *x0_tile = nullptr;         // input rows [rows_pad][4] (+ T-layout copy for the layer-0 dW of xyt nets)
@@ -336,23 +335,22 @@ hipError_t alloc_net_buffers(NetDesc& n, int rows_cap, bool own_coords) {
 void free_net(NetDesc& n) {
   (void)hipFree(n.acts); (void)hipFree(n.dz); (void)hipFree(n.masks); (void)hipFree(n.dz_last); (void)hipFree(n.pe_tile); (void)hipFree(n.out_buf); (void)hipFree(n.dout);
   (void)hipFree(n.coords); (void)hipFree(n.x0_tile);
-  (void)hipFree(n.d_fchunks); (void)hipFree(n.d_bchunks);
 }
 
 FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train) {
   FwdArgs a{};
-  a.wimg = h->img_f + n.f_base; a.chunks = n.d_fchunks; a.bias = h->bias_img + n.bias_base;
+  a.wimg = h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
   a.in = in; a.in1 = nullptr; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
-  a.NT = NT; a.nt_stride = NT; a.nchunks = (int)n.fchunks.size();
+  a.NT = NT; a.nt_stride = NT;
   return a;
 }
 
 BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
   BwdArgs a{};
-  a.wimg = h->img_b + n.b_base; a.chunks = n.d_bchunks; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
+  a.wimg = h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
   a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
-  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT; a.nchunks = (int)n.bchunks.size();
+  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT;
   return a;
 }
 
@@ -695,11 +693,6 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(hipMemset(h->params, 0, pc * 4)); CCHK(hipMemset(h->adam_m, 0, pc * 4)); CCHK(hipMemset(h->adam_v, 0, pc * 4));
   CCHK(hipMemset(h->pre_m, 0, pc * 4)); CCHK(hipMemset(h->pre_v, 0, pc * 4)); CCHK(hipMemset(h->grads, 0, pc * 4));
   CCHK(hipMemset(h->img_f, 0, fc * 4)); CCHK(hipMemset(h->img_b, 0, bc * 4)); CCHK(hipMemset(h->bias_img, 0, biasc * 4));
-  for (NetDesc& n : h->nets) if (n.used) {
-    CCHK(dalloc(&n.d_fchunks, n.fchunks.size())); CCHK(dalloc(&n.d_bchunks, n.bchunks.size()));
-    CCHK(hipMemcpy(n.d_fchunks, n.fchunks.data(), n.fchunks.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
-    CCHK(hipMemcpy(n.d_bchunks, n.bchunks.data(), n.bchunks.size() * sizeof(AfChunk), hipMemcpyHostToDevice));
-  }
   // batch buffers
   h->N = cfg->samples_batch;
   const int N = h->N, rows_pre = h->cfg.pretrain_batch;

@@ -10,7 +10,9 @@
 // ds_read_b128 per four MFMA steps, B = the previous layer's output, which is ALREADY in the right
 // registers (see "C-layout" in af_dev.h).  The four waves of a workgroup share the weight stream, which is
 // double-buffered in LDS in 64 KB chunks by global_load_lds (one barrier per chunk, 16 K MFMA cycles apart).
-// LDS: 2 x 64 KB.  Registers: 128 (activations) + 128 (accumulators) + 64 (A fragments) -> 1 wave / SIMD.
+// LDS: 2 x 64 KB weight buffers + 8 KB bias rows.  Registers: 128 (activations) + 128 (accumulators, AGPR) + 64
+// (A fragments) -> 1 wave / SIMD.  One kernel carries the chains of all four nets (k_mlp_*_multi, below): a launch is a
+// list of independent (net, row-tile range) parts.
 #include "mlp_common.h"
 
 // acc[T] += A(image in LDS) * b[B0 + 4*g + p]  for NG k-groups; a_lds already includes the lane offset
