@@ -250,3 +250,27 @@ def test_end_to_end_schedule_psnr_parity(small_video, golden):
     assert abs(p_hip - p_ref) < 0.1, (p_hip, p_ref)
     assert p_ref > 14.0 and ref[-1, 5] < 0.8 * ref[0, 5]                     # the schedule did fit something
     h.close()
+
+
+def test_more_error_paths(golden, small_video):
+    """Every entry point answers misuse with a negative status and a message, never a crash (include/atlasfit.h)."""
+    import ctypes
+    import aiod_amd
+    h = aiod_amd.AtlasFit(_cfg(golden))
+    lib = h.lib
+    bad = np.zeros(5, np.float32)
+    assert lib.af_set_params(h.h, aiod_amd.NET_ATLAS, bad.ctypes.data_as(ctypes.c_void_p), 5) == -1 and b"count" in lib.af_last_error(h.h)
+    assert lib.af_set_params(h.h, aiod_amd.NET_ALPHA, bad.ctypes.data_as(ctypes.c_void_p), 5) == -1          # net not part of a single-atlas handle
+    assert lib.af_param_count(h.h, aiod_amd.NET_MAPPING2) == 0 and lib.af_loss_width(h.h) == 8
+    assert lib.af_pretrain(h.h, aiod_amd.NET_ATLAS, 1, None, None, 0, None) == -1                               # only mapping nets pre-train
+    assert lib.af_pretrain(h.h, aiod_amd.NET_MAPPING2, 1, None, None, 0, None) == -1
+    assert lib.af_render_frame(h.h, 0, None, None) == -5                                                        # AF_ESTATE: no video yet
+    _upload(h, small_video)
+    assert lib.af_render_frame(h.h, int(golden["nframes"]), None, None) == -1
+    assert lib.af_train_steps(h.h, -1, 1, None, 0, None) == -1 and lib.af_train_steps(h.h, 0, 0, None, 0, None) == 0
+    idx = np.array([int(golden["nframes"]) * int(golden["resx"]) * int(golden["resy"])], np.int64)             # one past the last record
+    out = np.zeros((1, 16), np.float32)
+    assert lib.af_debug_records(h.h, idx.ctypes.data_as(ctypes.c_void_p), 1, out.ctypes.data_as(ctypes.c_void_p)) == -1
+    assert lib.af_resize_bilinear(0, None, 0, 4, 4, 3, None, 2, 2, 3, 1, 0, 1.0, 1.0, 0) == -1
+    assert lib.af_flow_consistency(0, None, None, 4, 4, None, 1, 0, 1.0, 0) == -1
+    h.close()
