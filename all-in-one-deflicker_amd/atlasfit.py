@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
-    "af_resize_bilinear", "af_flow_consistency",
+    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks",
 ]
 
 
@@ -167,6 +167,7 @@ def load_library(path=None):
         "af_debug_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32 * 3)]),
         "af_resize_bilinear": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i64, C.c_double, C.c_double, i32]),
         "af_flow_consistency": (i32, [i32, vp, vp, i32, i32, vp, i64, i64, C.c_float, i32]),
+        "af_debug_dw_clocks": (i32, [vp, i32, vp, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -384,6 +385,14 @@ class AtlasFit:
         out = np.empty((inds.size, 16), np.float32)
         self._chk(self.lib.af_debug_records(self.h, _ptr(inds), inds.size, _ptr(out)))
         return out
+
+    def dw_clocks(self, enable=True):
+        """(#CUs, 2) start / end s_memrealtime ticks (100 MHz) per workgroup of the most recent k_dw launch."""
+        out = np.zeros((1024, 2), np.uint64)
+        n = self.lib.af_debug_dw_clocks(self.h, int(enable), _ptr(out), 1024)
+        if n < 0:
+            self._chk(n)
+        return out[:n]
 
     def set_debug(self, on=True):
         self._chk(self.lib.af_set_debug(self.h, int(on)))

@@ -91,6 +91,7 @@ struct DwSeg { int job, t0, t1, slot; };
 struct DwArgs {
   const DwJob* jobs; const DwSeg* segs;   // segs: [gridDim.x][DW_MAXSEG], job<0 terminates
   float* partial;
+  unsigned long long* wg_clock;           // optional [gridDim.x][2]: s_memrealtime at workgroup start / end (balance diagnostics)
 };
 
 #if defined(__HIPCC__)

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const DwSeg* segs = a.segs + (size_t)blockIdx.x * DW_MAXSEG;
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
   for (int s = 0; s < DW_MAXSEG; ++s) {
     const DwSeg sg = segs[s];
     if (sg.job < 0) break;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
       default: break;
     }
   }
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 extern "C" int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s) {

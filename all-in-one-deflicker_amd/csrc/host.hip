@@ -92,6 +92,7 @@ struct af_handle {
   int cur_nseg = 0;
   // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
   Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
+  unsigned long long* dw_clock = nullptr;     // af_debug_dw_clocks: per-workgroup start/end times of the last k_dw launch
   // render
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
@@ -441,7 +442,7 @@ void plan_mapping_split(int ncu, int NT_map, int NT_atlas, int dep_rows, int& T1
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
 int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops) {
-  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
+  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
   {
     Timer t(h, T_ADAM);
     AdamArgs a{};
@@ -740,7 +741,7 @@ void af_destroy(af_handle* h) {
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
   (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table);
   (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
-  (void)hipFree(h->partial); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
+  (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
   (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1013,6 +1014,15 @@ int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[
   plan_mapping_split(ncu, NT_map, NT_atlas, dep_rows, out3[0], out3[1]);
   out3[2] = NT_map;
   return AF_OK;
+}
+
+int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
+  if (!h) return AF_EINVAL;
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  if (enable && !h->dw_clock) { HCHK(dalloc(&h->dw_clock, (size_t)h->ncu * 2)); HCHK(hipMemset(h->dw_clock, 0, (size_t)h->ncu * 16)); }
+  if (out && h->dw_clock) HCHK(hipMemcpy(out, h->dw_clock, (size_t)std::min(cap_wg, h->ncu) * 16, hipMemcpyDeviceToHost));
+  if (!enable && h->dw_clock) { (void)hipFree(h->dw_clock); h->dw_clock = nullptr; }
+  return h->ncu;
 }
 
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out) {

@@ -128,6 +128,9 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
  * out3 = {T1, T2, NT}: mapping row tiles [0,T1) form launch 1, [T1,T2) lead and [T2,NT) trail the atlas part of
  * launch 2 (DESIGN.md §2.1 "Packed launches"). */
 int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[3]);
+/* Balance diagnostics of k_dw: enable != 0 makes every later k_dw launch record s_memrealtime (100 MHz) at the start and
+ * end of each workgroup; out (nullable) receives [min(cap_wg, #CUs)][2] values of the most recent launch.  Returns #CUs. */
+int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
 /* Read back n 64-byte pixel records of the packed table: out [n][16] = rgb(3), d/dx rgb(3), d/dy rgb(3), fwd flow(2),
  * bwd flow(2), fwd mask, bwd mask, fg mask, for pixel-frame indices inds[n] (the k of get_tuples' column k). */
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
