@@ -249,7 +249,7 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   // DMA issue, fragment reads), fitted on MI355X by sweeping both constants (tools/dwsweep.sh: 50 / 30 run k_dw 2.5 %
   // faster than 20 / 20; the kernel time is flat within +-10 of either and climbs steeply outside).
   const double ovh = getenv("AF_DW_OVH") ? atof(getenv("AF_DW_OVH")) : 50.0, ovh_s = getenv("AF_DW_OVH_S") ? atof(getenv("AF_DW_OVH_S")) : 30.0;
-  const double seg_cost = 60.0;
+  const double seg_cost = getenv("AF_DW_SEG") ? atof(getenv("AF_DW_SEG")) : 60.0;
   auto tile_cost = [&](int j) { int To, Ti; return (double)shape_tiles(sc.jobs[j].shape, To, Ti) + (sc.jobs[j].shape == DW_8x8 ? ovh : ovh_s); };
   double work = 0;
   for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
