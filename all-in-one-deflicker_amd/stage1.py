@@ -367,6 +367,27 @@ def main(config, args, two_layer=False):
     return last_psnr
 
 
+def _run_reference_preprocessors(args, two_layer):
+    """The reference's stage-1 scripts first shell out to its RAFT flow precompute (stage1_neural_atlas.py:276-278)
+    and, for the fg/bg path, to a mask preprocessor (stage1_neural_atlas_seg.py:353-366).  Those stay the reference's own
+    PyTorch-ROCm code (out of scope here): when this CLI runs inside a checkout of the reference (the scripts exist
+    under ./src) it issues the same commands; elsewhere the inputs must already be on disk."""
+    import subprocess
+    if getattr(args, "skip_preprocess", False):
+        return
+    cmds = []
+    if os.path.exists("src/preprocess_optical_flow.py"):
+        cmds.append("python src/preprocess_optical_flow.py --vid-path %s --gpu %s " % (args.vid_path, args.gpu))
+    if two_layer:
+        if args.class_name == "portrait" and os.path.exists("src/preprocess_mask_portrait.py"):
+            cmds.append("python src/preprocess_mask_portrait.py --vid-path %s --gpu %s " % (args.vid_path, args.gpu))
+        elif args.class_name != "portrait" and os.path.exists("src/preprocess_mask_rcnn.py"):
+            cmds.append("python src/preprocess_mask_rcnn.py --vid-path %s --class_name %s --gpu %s " % (args.vid_path, args.class_name, args.gpu))
+    for cmd in cmds:
+        print(cmd)
+        subprocess.call(cmd, shell=True)
+
+
 def _cli(argv=None, two_layer=False):
     parser = argparse.ArgumentParser()
     parser.add_argument("--config", type=str, default="config_flow_100.json")
@@ -377,12 +398,14 @@ def _cli(argv=None, two_layer=False):
     if two_layer:
         parser.add_argument("--class_name", type=str, default="portrait", help="(reference flag; the mask preprocessors are external)")
     parser.add_argument("--seed", type=int, default=None, help="(extension) seed torch's RNG for reproducible runs")
+    parser.add_argument("--skip_preprocess", action="store_true", help="(extension) do not call the reference's flow / mask preprocessors even if ./src has them")
     parser.add_argument("--host_loader", action="store_true", help="(extension) build the input tensors with the numpy loader instead of the device one")
     args = parser.parse_args(argv)
     os.environ["CUDA_VISIBLE_DEVICES"] = "%d" % args.gpu        # reference :267-268 (HIP honours it on ROCm)
     os.environ.setdefault("HIP_VISIBLE_DEVICES", "%d" % args.gpu)
     args.device_ordinal = 0
     args.vid_path = os.path.join(args.root, args.vid_name)
+    _run_reference_preprocessors(args, two_layer)
     cfg_path = args.config if os.path.exists(args.config) else os.path.join("src/config", args.config)
     if os.path.exists(cfg_path):
         with open(cfg_path) as f:

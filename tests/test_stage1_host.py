@@ -213,3 +213,19 @@ def _write_video_into(root, v, name):
         np.save(fd / ("%s_%s.npy" % (names[f], names[f + 1])), v.optical_flows[:, :, :, f, 0].numpy())
         np.save(fd / ("%s_%s.npy" % (names[f + 1], names[f])), v.optical_flows_reverse[:, :, :, f + 1, 0].numpy())
     return d
+
+
+def test_pipeline_driver_builds_the_reference_command_sequence():
+    """run_pipeline.py mirrors test.py (test.py:17-43): frame extraction, stage 1 (ours, --gpu forwarded), stage 2."""
+    import argparse
+    import aiod_amd  # noqa: F401
+    from aiod_amd import run_pipeline as R
+    o = argparse.Namespace(video_name="data/test/Winter_Scenes_in_Holland.mp4", video_frame_folder=None, fps=10, gpu=3, class_name=None)
+    cmds = [c for _, c in R.build_commands(o)]
+    assert cmds[0] == "./data/test/Winter_Scenes_in_Holland"
+    assert cmds[1] == "ffmpeg -i data/test/Winter_Scenes_in_Holland.mp4 -vf fps=10 -start_number 0 ./data/test/Winter_Scenes_in_Holland/%05d.png"
+    assert cmds[2].endswith("stage1.py --vid_name Winter_Scenes_in_Holland --gpu 3")
+    assert cmds[3] == "python src/neural_filter_and_refinement.py --video_name Winter_Scenes_in_Holland --fps 10"
+    o = argparse.Namespace(video_name=None, video_frame_folder="clips/abc", fps=12, gpu=0, class_name="person")
+    cmds = [c for _, c in R.build_commands(o)]
+    assert cmds[0] == "mv abc ./data/test/abc" and "stage1_seg.py --vid_name abc --class_name person --gpu 0" in cmds[1]
