@@ -4,8 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, aiod_amd, bench
 two = "--two-layer" in sys.argv
+NB = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 10000
 dev = torch.device("cuda", 0)
-af = aiod_amd.AtlasFit(aiod_amd.default_config(768, 432, 80, two_layer=two))
+af = aiod_amd.AtlasFit(aiod_amd.default_config(768, 432, 80, two_layer=two, samples_batch=NB))
 video = bench.synth_video_device(768, 432, 80, seed=0, device=dev)
 if two:
     video = video + (bench.synth_fg_mask_device(768, 432, 80, seed=0, device=dev),)
