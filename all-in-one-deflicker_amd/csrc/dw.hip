@@ -4,28 +4,59 @@
 // The reduction dimension is the row batch (up to 90 000 rows), the output is at most 256x256, so the
 // rows are split over workgroups (split-K) by a static, cost-balanced schedule built on the host: each
 // workgroup walks a short list of segments (job, row-tile range) and writes one partial block per
-// segment; adam.hip sums the partials in a fixed order (deterministic, no float atomics).
+// segment; k_adam sums the partials in a fixed order (deterministic, no float atomics).
 //
-// Per segment a workgroup keeps the WHOLE dW block in accumulators (4 waves x up to 16 tiles of 32x32),
-// so both operands are streamed exactly once: 2 KB of HBM per row per 256x256 layer -> 64 FLOP/B,
-// i.e. ~2.4 TB/s at the FP32-MFMA peak.  Operand tiles ([feature][32 rows], T-layout) are copied to LDS
-// by global_load_lds with an XOR swizzle applied on the SOURCE address (the LDS image must stay
-// lane-linear), double-buffered, one barrier per 32-row tile (16 K MFMA cycles for an 8x8 job).
+// Per segment a workgroup keeps the WHOLE dW block in accumulators (4 waves x up to 16 tiles of 32x32 = all 256
+// AGPRs), so both operands are streamed exactly once: 2 KB of HBM per row per 256x256 layer -> 64 FLOP/B,
+// i.e. ~2.4 TB/s at the FP32-MFMA peak.
+//
+// Operand stream: a ring of DW_STAGES LDS slots, one STAGE = 16 rows (half a T-layout tile [feature][32 rows]) of
+// both operands, filled by global_load_lds (16 B per lane, LDS image lane-linear, the bank swizzle applied on the
+// SOURCE address).  Stage s+3 is issued while stage s is computed, so the `s_waitcnt vmcnt(N)` that publishes a
+// stage only covers pieces issued one and a half stages (~12 K MFMA cycles for an 8x8 job) earlier — it never drains
+// the younger stages (a one-tile-ahead double buffer with vmcnt(0) per tile left the matrix pipe idle 16 % of the
+// time, profiles/r1c_pmc_sq.txt).  One s_barrier per stage, placed mid-stage (see dw_segment); inside a stage every
+// LDS fragment read and every LDS-DMA issue sits behind its own MFMA (sched_group_barrier), never in a burst.
 // MFMA: A[m = out feature][k = row], B[k = row][n = in feature]; four consecutive k of one lane half are
 // one ds_read_b128.  db falls out of the A fragments for free.
 #include "af_dev.h"
 
-#define DW_BUF 65536
+#ifndef DW_ABL
+#define DW_ABL 0     // tools/dwbench.hip timing ablations of k_dw_bf: bit0 no operand split (raw bits fed to the MFMAs), bit1 one MFMA per
+#endif               // product instead of six, bit2 no explicit interleave (sched_group_barrier), bit3 packed-f32 subtract avoided
+#define DW_STAGES 4
+#define DW_LDS 131072
 
-// One 4 KB piece (256 lanes x 16 B) of a T-layout tile -> LDS with the 16-B-slot swizzle: physical slot c of
-// feature row f holds logical row-group c ^ ((f>>1)&7).  lane_off = the per-lane swizzled source offset.
-AF_DEV void dw_stage_piece(const char* src, char* dst, int it, int lane_off, int wave) {
-  af_glds16(src + it * 4096 + lane_off, dst + it * 4096 + wave * 1024);
+AF_DEV void dw_wait_vm(int n) {     // n is a small compile-time-known set: keep the immediates literal
+  switch (n) {
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+// s_barrier without the release/acquire fences of __syncthreads(): a fence makes hipcc drain vmcnt to 0 in front of the
+// barrier, which is exactly what the ring avoids.  Visibility of the LDS-DMA data is given by each wave's own counted
+// vmcnt wait in front of the barrier; the "memory" clobbers keep the compiler from moving LDS reads across it.
+AF_DEV void dw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 template <int TO, int TI, int TOW, int TIW>
 AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
                        int a0, int b0, bool store_w, bool store_db) {
+  constexpr int A_B = TO * 2048;                         // bytes of the A half-tile (TO x 32 features x 16 rows)
+  constexpr int NP = (TO + TI) * 128;                    // 16-B pieces per stage, A pieces first
+  constexpr int NI = (NP + 255) / 256;                   // LDS-DMA instructions per wave per stage
+  constexpr int SLOT = NI * 4096;                        // ring slot (>= the stage; the tail of an odd stage is padding)
+  static_assert(DW_STAGES * SLOT <= DW_LDS, "ring does not fit");
+  static_assert(NI == 2 || NI == 5 || NI == 8, "add the immediates to dw_wait_vm");
   const int m = lane & 31, h = lane >> 5;
   f32x16 acc[TOW][TIW];
   float dbacc[TOW];
@@ -37,62 +68,83 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   }
-  constexpr int a_bytes = TO * 4096, b_bytes = TI * 4096;
-  constexpr int NPIECE = TO + TI, PER_G = (NPIECE + 3) / 4;
-  const char* Ab = (const char*)jb.A;
-  const char* Bb = (const char*)jb.B;
-  const size_t a_ts = (size_t)jb.a_stride * 4, b_ts = (size_t)jb.b_stride * 4;
-  const int lane_off = ((((tid >> 3) << 3) + ((tid & 7) ^ ((tid >> 4) & 7))) << 4);
-
-  auto stage_piece = [&](int t, char* buf, int i) {     // piece i of tile t: first TO pieces = A, rest = B
-    if (i < TO) dw_stage_piece(Ab + t * a_ts, buf, i, lane_off, wave);
-    else        dw_stage_piece(Bb + t * b_ts, buf + a_bytes, i - TO, lane_off, wave);
+  // Per-lane source of each of the NI pieces this lane moves per stage.  Piece i = 256 k + tid of a stage lands at LDS
+  // byte 16 i of the slot: feature row f = li >> 2 (li = index inside its operand), physical 16-B slot li & 3, which
+  // holds logical row group c = (li & 3) ^ ((f >> 2) & 3) — so the 16 lanes of a ds_read_b128 group hit 16 banks sets.
+  const char* src[NI]; uint32_t tstr[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    int i = k * 256 + tid;
+    bool is_a = i < TO * 128;
+    int li = is_a ? i : i - TO * 128;
+    if (i >= NP) { li = 0; is_a = true; }               // padding lanes of an odd stage: re-read piece 0 into the pad
+    const int f = li >> 2, c = (li & 3) ^ ((f >> 2) & 3);
+    src[k] = (const char*)(is_a ? jb.A : jb.B) + f * 128 + c * 16;
+    tstr[k] = (is_a ? jb.a_stride : jb.b_stride) * 4u;
+  }
+  const int S = 2 * (sg.t1 - sg.t0);                     // stages of this segment
+  auto issue = [&](int s, int k) {                       // piece k of stage s -> ring slot s & 3
+    const int sc = s < S ? s : S - 1;                    // past the end: harmless re-stage (keeps the vmcnt arithmetic uniform)
+    const char* g = src[k] + (size_t)(sg.t0 + (sc >> 1)) * tstr[k] + (sc & 1) * 64;
+    af_glds16(g, smem + (s & (DW_STAGES - 1)) * SLOT + k * 4096 + wave * 1024);
   };
 #pragma unroll
-  for (int i = 0; i < NPIECE; ++i) stage_piece(sg.t0, smem, i);
+  for (int s = 0; s < DW_STAGES - 1; ++s)
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue(s, k);
 
-  const int swz = (m >> 1) & 7;
-  int goff[4];
+  const int sw = (m >> 2) & 3;
+  int goff[2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) goff[g] = m * 128 + (((2 * g + h) ^ swz) << 4);
+  for (int g = 0; g < 2; ++g) goff[g] = m * 64 + (((2 * g + h) ^ sw) << 4);
+  const int abase = a0 * 2048, bbase = A_B + b0 * 2048;
 
-  for (int t = sg.t0; t < sg.t1; ++t) {
-    af_wait_vm0();
-    __syncthreads();
-    const int cur = (t - sg.t0) & 1;
-    const int tn = t + 1 < sg.t1 ? t + 1 : t;           // last tile: harmless re-stage into the idle buffer
-    char* nb = smem + (cur ^ 1) * DW_BUF;
-    const char* abuf = smem + cur * DW_BUF + a0 * 4096;
-    const char* bbuf = smem + cur * DW_BUF + a_bytes + b0 * 4096;
-    f32x4 af[2][TOW], bf[2][TIW];
+  // Software pipeline: the barrier that publishes stage s+1 sits in the MIDDLE of stage s, between its two k-groups.
+  // Behind it the second group prefetches the first fragments of stage s+1 and issues the DMA of stage s+3 (into the
+  // slot stage s-1 left: every wave is past stage s-1 once it is past this barrier), so neither the LDS latency of a
+  // stage's first fragment reads nor the barrier skew between the four waves is ever in front of an idle matrix pipe.
+  f32x4 af[2][TOW], bf[2][TIW];
+  auto read_frags = [&](int buf, const char* slot, int g) {
 #pragma unroll
-    for (int x = 0; x < TOW; ++x) af[0][x] = *(const f32x4*)(abuf + x * 4096 + goff[0]);
+    for (int x = 0; x < TOW; ++x) af[buf][x] = *(const f32x4*)(slot + abase + x * 2048 + goff[g]);
 #pragma unroll
-    for (int y = 0; y < TIW; ++y) bf[0][y] = *(const f32x4*)(bbuf + y * 4096 + goff[0]);
+    for (int y = 0; y < TIW; ++y) bf[buf][y] = *(const f32x4*)(slot + bbase + y * 2048 + goff[g]);
+  };
+  auto group = [&](int g) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g + 1 < 4) {
+    for (int x = 0; x < TOW; ++x) dbacc[x] += (af[g][x][0] + af[g][x][1]) + (af[g][x][2] + af[g][x][3]);
 #pragma unroll
-        for (int x = 0; x < TOW; ++x) af[(g + 1) & 1][x] = *(const f32x4*)(abuf + x * 4096 + goff[g + 1]);
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int y = 0; y < TIW; ++y) bf[(g + 1) & 1][y] = *(const f32x4*)(bbuf + y * 4096 + goff[g + 1]);
-      }
+      for (int x = 0; x < TOW; ++x)
 #pragma unroll
-      for (int i = g * PER_G; i < (g + 1) * PER_G && i < NPIECE; ++i) stage_piece(tn, nb, i);   // next tile, in this group's MFMA shadow
+        for (int y = 0; y < TIW; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][x][p], bf[g][y][p], acc[x][y], 0, 0, 0);
 #pragma unroll
-      for (int x = 0; x < TOW; ++x) dbacc[x] += (af[g & 1][x][0] + af[g & 1][x][1]) + (af[g & 1][x][2] + af[g & 1][x][3]);
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int x = 0; x < TOW; ++x)
-#pragma unroll
-          for (int y = 0; y < TIW; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][x][p], bf[g & 1][y][p], acc[x][y], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 4 * TOW * TIW; ++i) {            // one LDS read and one LDS-DMA issue behind each MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  dw_wait_vm(2 * NI);                                    // stage 0 has landed
+  dw_barrier();
+  read_frags(0, smem, 0);
+  for (int s = 0; s < S; ++s) {
+    const char* slot = smem + (s & (DW_STAGES - 1)) * SLOT;
+    const char* nslot = smem + ((s + 1) & (DW_STAGES - 1)) * SLOT;
+    read_frags(1, slot, 1);
+    group(0);
+    dw_wait_vm(NI);                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_barrier();                                        // ... for every wave; and every wave is done with stage s-1
+    read_frags(0, nslot, 0);                             // past the last stage: a harmless read of a re-staged slot
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);
+    group(1);
   }
-  af_wait_vm0();
-  __syncthreads();   // everyone done reading LDS (and the trailing re-stage landed) before the next segment restages
+  dw_wait_vm(0);
+  dw_barrier();      // everyone done reading LDS (and the trailing re-stages landed) before the next segment restages
 
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
   constexpr int pld = TI * 32;
@@ -112,6 +164,214 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
     const float tot = dbacc[x] + __shfl_xor(dbacc[x], 32);
     if (store_db && h == 0) af_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same contraction on the bf16 matrix pipe with fp32-faithful operands ("bf16x6"): every fp32 operand element is
+// split in registers into three bf16 values hi + mid + lo (8 + 8 + 8 mantissa bits; the two residuals are exact fp32
+// subtractions, so hi + mid + lo == x to within 2^-25 |x|), and a product a*b is accumulated as the six partial
+// products hh + hm + mh + mm + hl + lh in the MFMA's fp32 accumulator.  The dropped terms (ml, lm, ll) are <= 2^-23
+// |ab| — the size of the rounding of ONE fp32 multiply — so the result carries fp32-level round-off (measured against
+// fp64 on a 90 000-row contraction: 1.5e-7 relative, vs 2.3e-7 for a plain fp32 GEMM; tests/test_split_precision.py
+// restates the arithmetic on the CPU).  v_mfma_f32_32x32x16_bf16 retires K = 16 in 32 cycles where the fp32 MFMA needs
+// 8 x 64: six of them per 16 rows are 2.7x faster, which moves this kernel from the matrix pipe onto HBM (2 KB per row
+// per 256x256 layer, read once).
+// One stage of the LDS ring (16 rows) is exactly one k-step: lane (m, h) holds rows 8h..8h+7 of feature m — two
+// ds_read_b128 of the T-layout half tile per operand tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DwSplit { u32x4 h, m, l; };
+AF_DEV uint32_t dw_pk(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }   // v_cvt_pk_bf16_f32 (RNE)
+AF_DEV float dw_sub(float a, float b) {
+  if constexpr (DW_ABL & 8) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // keeps hipcc from SLP-packing into v_pk_add_f32
+  return a - b;
+}
+AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
+  DwSplit s;
+  if constexpr (DW_ABL & 1) {
+    s.h = __builtin_bit_cast(u32x4, lo4); s.m = __builtin_bit_cast(u32x4, hi4); s.l = s.h;
+    return s;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = i < 2 ? lo4[2 * i] : hi4[2 * i - 4], b = i < 2 ? lo4[2 * i + 1] : hi4[2 * i - 3];
+    const uint32_t h = dw_pk(a, b);
+    const float ra = dw_sub(a, __builtin_bit_cast(float, h << 16)), rb = dw_sub(b, __builtin_bit_cast(float, h & 0xffff0000u));
+    const uint32_t m = dw_pk(ra, rb);
+    const float qa = dw_sub(ra, __builtin_bit_cast(float, m << 16)), qb = dw_sub(rb, __builtin_bit_cast(float, m & 0xffff0000u));
+    s.h[i] = h; s.m[i] = m; s.l[i] = dw_pk(qa, qb);
+  }
+  return s;
+}
+AF_DEV f32x16 dw_mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int TO, int TI, int TOW, int TIW>
+AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
+                          int a0, int b0, bool store_w, bool store_db) {
+  constexpr int A_B = TO * 2048;
+  constexpr int NP = (TO + TI) * 128;
+  constexpr int NI = (NP + 255) / 256;
+  constexpr int SLOT = NI * 4096;
+  static_assert(DW_STAGES * SLOT <= DW_LDS, "ring does not fit");
+  static_assert(NI == 2 || NI == 5 || NI == 8, "add the immediates to dw_wait_vm");
+  const int m = lane & 31, h = lane >> 5;
+  f32x16 acc[TOW][TIW];
+  float dbacc[TOW];
+#pragma unroll
+  for (int x = 0; x < TOW; ++x) {
+    dbacc[x] = 0.f;
+#pragma unroll
+    for (int y = 0; y < TIW; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  }
+  // same ring / source swizzle as dw_segment; per lane only a 32-bit offset per piece (the operand an instruction reads
+  // is wave-uniform except for the one instruction that straddles A|B when TO is odd)
+  uint32_t soff[NI]; bool sel_a[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    int i = k * 256 + tid;
+    bool is_a = i < TO * 128;
+    int li = is_a ? i : i - TO * 128;
+    if (i >= NP) { li = 0; is_a = true; }
+    const int f = li >> 2, c = (li & 3) ^ ((f >> 2) & 3);
+    soff[k] = (uint32_t)(f * 128 + c * 16);
+    sel_a[k] = is_a;
+  }
+  const int S = 2 * (sg.t1 - sg.t0);
+  auto issue = [&](int s, int k) {
+    const int sc = s < S ? s : S - 1;
+    const size_t t = (size_t)(sg.t0 + (sc >> 1));
+    const char* ga = (const char*)jb.A + t * jb.a_stride * 4u + (sc & 1) * 64;      // wave-uniform
+    const char* gb = (const char*)jb.B + t * jb.b_stride * 4u + (sc & 1) * 64;
+    const bool all_a = (k + 1) * 256 <= TO * 128, all_b = k * 256 >= TO * 128 && (k + 1) * 256 <= NP;
+    const char* g = all_a ? ga : (all_b ? gb : (sel_a[k] ? ga : gb));
+    af_glds16(g + soff[k], smem + (s & (DW_STAGES - 1)) * SLOT + k * 4096 + wave * 1024);
+  };
+#pragma unroll
+  for (int s = 0; s < DW_STAGES - 1; ++s)
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue(s, k);
+
+  const int sw = (m >> 2) & 3;
+  const int off0 = m * 64 + (((2 * h) ^ sw) << 4), off1 = m * 64 + (((2 * h + 1) ^ sw) << 4);     // rows 8h..8h+3, 8h+4..8h+7
+  const int abase = a0 * 2048, bbase = A_B + b0 * 2048;
+  f32x4 ra[2][TOW][2];                                   // raw A fragments, double-buffered across stages
+  f32x4 rb[TIW][2];                                      // raw B fragments: column y is refreshed for the next stage while column y runs
+  auto read_a = [&](int buf, const char* slot) {
+#pragma unroll
+    for (int x = 0; x < TOW; ++x) { ra[buf][x][0] = *(const f32x4*)(slot + abase + x * 2048 + off0); ra[buf][x][1] = *(const f32x4*)(slot + abase + x * 2048 + off1); }
+  };
+  auto read_b = [&](int y, const char* slot) {
+    rb[y][0] = *(const f32x4*)(slot + bbase + y * 2048 + off0); rb[y][1] = *(const f32x4*)(slot + bbase + y * 2048 + off1);
+  };
+  // One stage: split this stage's A operands, publish stage s+1 (counted wait + barrier), start the reads of its raw A
+  // fragments and the DMA of stage s+3, then column by column: the 6 x TOW products of column y run with the split of
+  // column y+1 and the refresh of column y's raw registers (stage s+1) in their shadow.
+  auto stage = [&](int s, int cur) {
+    const char* nslot = smem + ((s + 1) & (DW_STAGES - 1)) * SLOT;      // past the last stage: harmless reads of a re-staged slot
+    DwSplit sa[TOW];
+#pragma unroll
+    for (int x = 0; x < TOW; ++x) {
+      sa[x] = dw_split8(ra[cur][x][0], ra[cur][x][1]);
+      const f32x4 t = ra[cur][x][0] + ra[cur][x][1];
+      dbacc[x] += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    DwSplit sb = dw_split8(rb[0][0], rb[0][1]);
+    dw_wait_vm(NI);                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_barrier();                                        // ... for every wave; every wave holds what it needs of stage s-1
+    read_a(cur ^ 1, nslot);
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);      // into the slot stage s-1 left
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int y = 0; y < TIW; ++y) {
+      DwSplit sbn = sb;
+      if (y + 1 < TIW) sbn = dw_split8(rb[y + 1][0], rb[y + 1][1]);
+      read_b(y, nslot);                                  // column y of stage s was split one region ago: its registers take stage s+1
+      if constexpr (!(DW_ABL & 2)) {
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.l, acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].l, sb.h, acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].m, sb.m, acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.m, acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].m, sb.h, acc[x][y]);
+      }
+#pragma unroll
+      for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.h, acc[x][y]);
+      if constexpr (!(DW_ABL & 4)) {
+#pragma unroll
+        for (int i = 0; i < 6 * TOW; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sb = sbn;
+    }
+  };
+  dw_wait_vm(2 * NI);                                    // stage 0 has landed
+  dw_barrier();
+  read_a(0, smem);
+#pragma unroll
+  for (int y = 0; y < TIW; ++y) read_b(y, smem);
+  for (int s = 0; s < S; s += 2) {                       // S is even (two stages per 32-row tile): no register copies between stages
+    stage(s, 0);
+    stage(s + 1, 1);
+  }
+  dw_wait_vm(0);
+  dw_barrier();
+
+  float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
+  constexpr int pld = TI * 32;
+  const auto rblk = af_rsrc_uniform(blk, jb.part_blk * 4);
+  if (store_w) {
+    const int voff = ((a0 * 32 + 4 * h) * pld + b0 * 32 + m) * 4;
+#pragma unroll
+    for (int x = 0; x < TOW; ++x)
+#pragma unroll
+      for (int y = 0; y < TIW; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          af_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
+  }
+#pragma unroll
+  for (int x = 0; x < TOW; ++x) {
+    const float tot = dbacc[x] + __shfl_xor(dbacc[x], 32);
+    if (store_db && h == 0) af_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const DwSeg* segs = a.segs + (size_t)blockIdx.x * DW_MAXSEG;
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+  for (int s = 0; s < DW_MAXSEG; ++s) {
+    const DwSeg sg = segs[s];
+    if (sg.job < 0) break;
+    const DwJob jb = a.jobs[sg.job];
+    switch (jb.shape) {      // 8x8: each wave a 4x4 block of output tiles (8 operand tiles to read and split per stage, the minimum)
+      case DW_8x8: dw_segment_bf<8, 8, 4, 4>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2); break;
+      case DW_8x2: dw_segment_bf<8, 2, 2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_8x1: dw_segment_bf<8, 1, 2, 1>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_1x8: dw_segment_bf<1, 8, 1, 2>(jb, sg, a.partial, smem, tid, wave, lane, 0, 2 * wave, true, wave == 0); break;
+      case DW_1x2: dw_segment_bf<1, 2, 1, 1>(jb, sg, a.partial, smem, tid, wave, lane, 0, wave & 1, wave < 2, wave == 0); break;
+      default: break;
+    }
+  }
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
@@ -137,10 +397,14 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-extern "C" int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s) {
-  hipLaunchKernelGGL(k_dw, dim3(nwg), dim3(256), 2 * DW_BUF, s, *a);
+// mode 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32); mode 1: bf16x6 split operands on the bf16 matrix pipe
+extern "C" int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL(k_dw, dim3(nwg), dim3(256), DW_LDS, s, *a);
+  else           hipLaunchKernelGGL(k_dw_bf, dim3(nwg), dim3(256), DW_LDS, s, *a);
   return (int)hipGetLastError();
 }
 extern "C" int af_dw_init() {
-  return (int)hipFuncSetAttribute((const void*)k_dw, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_BUF);
+  hipError_t e = hipFuncSetAttribute((const void*)k_dw, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipFuncSetAttribute((const void*)k_dw_bf, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
 }

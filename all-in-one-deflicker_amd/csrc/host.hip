@@ -24,7 +24,7 @@ int af_launch_fwd16(int net, const FwdArgs* a, hipStream_t s);
 int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s);
 int af_mlp16_init();
 int af_mlp_chunk_bytes(int net, int which);
-int af_launch_dw(const DwArgs* a, int nwg, hipStream_t s);
+int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s);
 int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
 int af_launch_prep(const PrepArgs* a, hipStream_t s);
@@ -97,6 +97,7 @@ struct af_handle {
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
+  int dw_mode = 1;                            // k_dw arithmetic: 1 = bf16x6 split operands on the bf16 matrix pipe (dw.hip), 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -442,7 +443,7 @@ void plan_mapping_split(int ncu, int NT_map, int NT_atlas, int dep_rows, int& T1
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
 int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops) {
-  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock}; LCHK(af_launch_dw(&d, sc.nwg, h->stream)); }
+  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock}; LCHK(af_launch_dw(&d, sc.nwg, h->dw_mode, h->stream)); }
   {
     Timer t(h, T_ADAM);
     AdamArgs a{};
@@ -666,6 +667,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (e != hipSuccess) { g_create_error = std::string("af_create: hipSetDevice: ") + hipGetErrorString(e); return AF_EHIP; }
   af_handle* h = new af_handle();
   h->cfg = *cfg; h->device = device_ordinal; h->seg = seg;
+  if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : 1;
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
   auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
@@ -840,6 +842,7 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
   return AF_OK;
 }
 
+int af_set_dw_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->dw_mode = mode; return AF_OK; }
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
 int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
 int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset) {

@@ -15,6 +15,27 @@
 // list of independent (net, row-tile range) parts.
 #include "mlp_common.h"
 
+#ifndef AF_SGB
+#define AF_SGB 1     // explicit MFMA / memory-instruction interleave (sched_group_barrier) inside every k-group
+#endif
+#ifndef AF_AFRAG
+#define AF_AFRAG 1   // A fragments in AGPRs (see lds_frag)
+#endif
+
+// One A fragment (four consecutive k of one output row) from the LDS weight image, pinned to the accumulator half of
+// the register file: ds_read_b128 writes AGPRs directly and the MFMA takes its A operand from there, so the 64
+// fragment registers do not compete with the 128 activation registers for the 256 architectural VGPRs (with all of
+// them in VGPRs the allocator is full and sinks every group's reads to the end of the previous group, where their
+// latency is exposed behind an s_waitcnt lgkmcnt(0)).
+AF_DEV f32x4 lds_frag(const char* p) { return *(const f32x4*)p; }
+// The pin sits at the fragment's first USE (top of its k-group), not at the load: the compiler's s_waitcnt for the
+// read lands there too, a whole group (32 MFMAs) after the read was issued.
+AF_DEV void pin_acc(f32x4& v) {
+#if AF_AFRAG
+  asm("" : "+a"(v));
+#endif
+}
+
 // acc[T] += A(image in LDS) * b[B0 + 4*g + p]  for NG k-groups; a_lds already includes the lane offset
 // (h*MPAD + j)*16.  NP < 4 skips reduction indices that are structurally zero.  hook(g) is called once per
 // k-group right after that group's A-fragment reads were issued: work placed there (LDS-DMA issue of the
@@ -25,16 +46,18 @@ AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a
   constexpr int MPAD = MT * 32;
   f32x4 a[2][MT];
 #pragma unroll
-  for (int T = 0; T < MT; ++T) a[0][T] = *(const f32x4*)(a_lds + T * 32 * 16);
+  for (int T = 0; T < MT; ++T) a[0][T] = lds_frag(a_lds + T * 32 * 16);
   if constexpr (AF_ABL & 8) {
 #pragma unroll
     for (int T = 0; T < MT; ++T) a[1][T] = a[0][T];
   }
   auto step = [&](auto gi) {
     constexpr int g = decltype(gi)::value;
+#pragma unroll
+    for (int T = 0; T < MT; ++T) pin_acc(a[g & 1][T]);
     if constexpr (g + 1 < NG && !(AF_ABL & 8)) {
 #pragma unroll
-      for (int T = 0; T < MT; ++T) a[(g + 1) & 1][T] = *(const f32x4*)(a_lds + ((g + 1) * 2 * MPAD + 32 * T) * 16);
+      for (int T = 0; T < MT; ++T) a[(g + 1) & 1][T] = lds_frag(a_lds + ((g + 1) * 2 * MPAD + 32 * T) * 16);
     }
     hook(gi);
 #pragma unroll
@@ -48,6 +71,17 @@ AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a
         acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][T][p], b[B0 + g * 4 + p], acc[T], 0, 0, 0);
       }
     }
+#if AF_SGB
+    // Issue order inside the group: one LDS fragment read and one VMEM instruction (LDS-DMA piece / tile store) behind
+    // each MFMA, so that every memory instruction issues in the shadow of a 64-cycle MFMA instead of in one burst
+    // behind which the matrix pipe drains (hipcc's own order: 24 MFMAs, then 8 reads + 2 DMA + up to 16 stores).
+#pragma unroll
+    for (int i = 0; i < NP * MT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+#endif
     if constexpr (!(AF_ABL & 16)) __builtin_amdgcn_sched_barrier(0);     // keep each group's DMA / stores inside its own MFMA shadow
   };
   (step(GIdx<Gs>{}), ...);

@@ -134,6 +134,11 @@ int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
 /* Read back n 64-byte pixel records of the packed table: out [n][16] = rgb(3), d/dx rgb(3), d/dy rgb(3), fwd flow(2),
  * bwd flow(2), fwd mask, bwd mask, fg mask, for pixel-frame indices inds[n] (the k of get_tuples' column k). */
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
+/* Arithmetic of the weight-gradient GEMMs (k_dw): 1 (default) = fp32-faithful "bf16x6" — each fp32 operand split in
+ * registers into three bf16 values (24 mantissa bits) and the six leading partial products accumulated in fp32 on the
+ * bf16 matrix pipe; 0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Both carry fp32-level round-off
+ * (tests/test_split_precision.py, tests/test_gpu_dw_modes.py); mode 0 is kept as the cross-check.  Env AF_DW_FP32=1 selects 0. */
+int af_set_dw_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);

@@ -1,0 +1,113 @@
+"""BASELINE configs[0] run through the REFERENCE's own modules: the acceptance metric on a BASELINE config.
+
+For each seed: the seeded synthetic 80-frame 160x90 video (the sample mp4 is 640x360, --down 4), the
+reference's `IMLP`s initialised under `torch.manual_seed(seed)`, the reference's `pre_train_mapping`
+(100 x F steps, unwrap_utils.py:176-198), then `iters_num` = 1001 iterations of the loop body of
+src/stage1_neural_atlas.py:153-231 driven with the reference's own loss functions and `torch.optim.Adam`
+(same harness as oracle/make_golden.py), and finally the mean PSNR of the reconstructed frames
+(evaluate.py:640-661,740-743, restated in oracle/atlas_oracle.py — evaluate.py itself needs cv2/skimage).
+
+Every random draw comes from torch's global CPU generator in the reference's order (model init, pre-train rows
+then columns per step, one `torch.randint(P, (N, 1))` per loop iteration), so the GPU test can replay the very
+same draws from the seed alone (tests/test_gpu_c1.py) — the fixture only stores the results:
+
+    tests/golden/c1_reference.npz   per seed: PSNR after the pre-train, final PSNR (mean + per frame), the six
+                                    loss terms every 100 iterations, wall-clock of the CPU run
+
+Build container only (imports /root/reference read-only; ~17 min of CPU per seed):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_c1.py [--seeds 0 1 2] [--threads 6]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("AF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+for _name in ("cv2", "imageio"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+
+from src.models.stage_1.implicit_neural_networks import IMLP                       # noqa: E402
+from src.models.stage_1.unwrap_utils import get_tuples, pre_train_mapping           # noqa: E402
+
+from oracle import atlas_oracle as O                                                # noqa: E402
+from oracle.make_golden import ref_iteration                                        # noqa: E402
+
+RESX, RESY, NF = 160, 90, 80           # configs[0]: Winter_Scenes_in_Holland 640x360 / 4, 80 frames
+ITERS = 1001                           # BASELINE configs[0] iters_num=1000 -> evaluate at iteration 1000
+PRETRAIN_ITERS = 100                   # config_flow_100.json:36
+LOG_EVERY = 100
+
+
+def shipped_config():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("af_atlasfit_cfg", os.path.join(ROOT, "all-in-one-deflicker_amd", "atlasfit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return dict(mod.REFERENCE_CONFIG)
+
+
+def run_seed(seed, c):
+    video = O.synthetic_video(RESX, RESY, NF, seed=seed)
+    torch.manual_seed(seed)
+    # stage1_neural_atlas.py:112-128 (mapping first, then atlas)
+    rm = IMLP(input_dim=3, output_dim=2, hidden_dim=256, use_positional=False, positional_dim=4, num_layers=6, skip_layers=[], verbose=False)
+    ra = IMLP(input_dim=2, output_dim=3, hidden_dim=256, use_positional=True, positional_dim=10, num_layers=8, skip_layers=[4, 7], verbose=False)
+    opt = torch.optim.Adam([{"params": list(rm.parameters())}, {"params": list(ra.parameters())}], lr=0.0001)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        pre_train_mapping(rm, NF, c["uv_mapping_scale"], resx=RESX, resy=RESY, larger_dim=video.larger_dim, device="cpu",
+                          pretrain_iters=PRETRAIN_ITERS)
+    t_pre = time.time() - t0
+    psnr_pre, _ = O.mean_psnr(rm, ra, video)
+    jif_all = get_tuples(NF, video.video_frames)
+    N = c["samples_batch"]
+    curve = []
+    t0 = time.time()
+    for i in range(ITERS):
+        inds = torch.randint(jif_all.shape[1], (np.int64(N * 1.0), 1))
+        loss, terms = ref_iteration(i, jif_all[:, inds], video, rm, ra, c)
+        opt.zero_grad(); loss.backward(); opt.step()
+        if i % LOG_EVERY == 0:
+            curve.append(terms)
+            print("seed %d iter %4d  total %.4f  rgb %.5f  (%.0f s)" % (seed, i, terms[5], terms[0], time.time() - t0), flush=True)
+    t_loop = time.time() - t0
+    psnr, per = O.mean_psnr(rm, ra, video)
+    print("seed %d: PSNR %.4f dB after the pre-train -> %.4f dB after %d iterations (pre-train %.0f s, loop %.0f s)" % (seed, psnr_pre, psnr, ITERS, t_pre, t_loop), flush=True)
+    return dict(psnr_pre=psnr_pre, psnr=psnr, per_frame=np.array(per), curve=np.array(curve, np.float64), t_pre=t_pre, t_loop=t_loop,
+                video_checksum=float(video.video_frames.double().sum()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c1_reference.npz"))
+    args = ap.parse_args()
+    if args.threads > 0:
+        torch.set_num_threads(args.threads)
+    c = shipped_config()
+    res = [run_seed(s, c) for s in args.seeds]
+    np.savez_compressed(
+        args.out, seeds=np.array(args.seeds), resx=RESX, resy=RESY, nframes=NF, iters=ITERS, pretrain_iters=PRETRAIN_ITERS, log_every=LOG_EVERY,
+        psnr_pre=np.array([r["psnr_pre"] for r in res]), psnr=np.array([r["psnr"] for r in res]),
+        psnr_per_frame=np.stack([r["per_frame"] for r in res]), curves=np.stack([r["curve"] for r in res]),
+        cpu_seconds=np.array([[r["t_pre"], r["t_loop"]] for r in res]), threads=torch.get_num_threads(),
+        video_checksum=np.array([r["video_checksum"] for r in res]),
+    )
+    print("written", args.out, "PSNR", [r["psnr"] for r in res])
+
+
+if __name__ == "__main__":
+    main()

@@ -4,9 +4,13 @@ check the oracle restatement (oracle/atlas_oracle.py, seg section) against them 
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_seg.py        (build container only)
 
-The trajectory starts from the seeded torch initialisation (RNG-only, hence reproducible anywhere with the
-same torch build), so no start-state blob is needed; the pre-trained regime is covered on the GPU by
-oracle-vs-HIP comparisons that need no fixture.
+The trajectory starts where the reference's loop starts (stage1_neural_atlas_seg.py:173-179): the seeded torch
+initialisation (RNG-only, hence reproducible anywhere with the same torch build) with BOTH mapping nets run through
+the reference's `pre_train_mapping`.  The two pre-trained mapping nets are stored in full in
+`seg_small_start.npz` (the atlas and alpha nets keep their seeded init), exactly like the single-atlas fixture's
+`single_small_start.npz`.  From that well-conditioned state (rigidity ~3, not ~1.3e3) fp32 implementations agree to
+~1e-5, so the GPU tests assert BASELINE.json's 1e-3 strictly on every iteration; the generator prints how far the
+reference's own fp32 trajectory is from an fp64 twin as a diagnostic.
 """
 import os
 import sys
@@ -27,7 +31,7 @@ for _name in ("cv2", "imageio"):
 from src.models.stage_1.implicit_neural_networks import IMLP                                    # noqa: E402
 from src.models.stage_1.loss_utils import (get_gradient_loss, get_rigidity_loss, get_optical_flow_loss,   # noqa: E402
                                            get_optical_flow_alpha_loss)
-from src.models.stage_1.unwrap_utils import get_tuples                                           # noqa: E402
+from src.models.stage_1.unwrap_utils import get_tuples, pre_train_mapping                        # noqa: E402
 
 from oracle import atlas_oracle as O                                                             # noqa: E402
 
@@ -46,6 +50,7 @@ CONFIG = {
 }
 RESX, RESY, NF, VSEED, WSEED = 40, 24, 6, 5, 4321
 K_ITERS = 10     # global rigidity switches off after iteration 5, alpha bootstrapping after iteration 7
+PRE_ITERS = 40   # pre_train_mapping iterations (x NF steps of 10 000 samples) on each mapping net before the loop
 
 
 def ref_models(seed):
@@ -119,13 +124,33 @@ def main():
         fwd_map2 = rm[1](rows_xyt); fwd_alpha = rm[3](rows_xyt)
         assert torch.equal(fwd_map2, om[1](rows_xyt)) and torch.equal(fwd_alpha, om[3](rows_xyt))
 
+    init_sums = [float(np.abs(O.flat_params(m)).sum()) for m in rm]
+    # ---- pre_train_mapping of both mapping nets with the reference's function (stage1_neural_atlas_seg.py:173-179);
+    # the oracle twins start from the same post-pre-train parameters
+    import contextlib, io
+    torch.manual_seed(WSEED + 1)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        pre_train_mapping(rm[0], NF, c["uv_mapping_scale"], resx=RESX, resy=RESY, larger_dim=video.larger_dim, device="cpu", pretrain_iters=PRE_ITERS)
+        pre_train_mapping(rm[1], NF, c["uv_mapping_scale"], resx=RESX, resy=RESY, larger_dim=video.larger_dim, device="cpu", pretrain_iters=PRE_ITERS)
+    for r, o in zip(rm[:2], om[:2]):
+        o.load_state_dict(r.state_dict())
+    start_m1, start_m2 = O.flat_params(rm[0]), O.flat_params(rm[1])
+    # fp64 twin (diagnostic only): how much fp32 round-off the reference's own trajectory carries from this state
+    import copy
+    m64 = [copy.deepcopy(m).double() for m in om]
+    for m in m64:
+        if m.use_positional:
+            m.b = m.b.double()
+    v64 = O.SegVideo(video.video_frames.double(), video.optical_flows.double(), video.optical_flows_reverse.double(),
+                     video.optical_flows_mask, video.optical_flows_reverse_mask, video.mask_frames.double())
+    tr64 = O.SegAtlasTrainer(c, v64, models=m64)
+
     jif_all = get_tuples(NF, video.video_frames)
     opt = torch.optim.Adam([{"params": list(rm[0].parameters())}, {"params": list(rm[1].parameters())},
                             {"params": list(rm[3].parameters())}, {"params": list(rm[2].parameters())}], lr=0.0001)
     tr = O.SegAtlasTrainer(c, video, models=om)
     torch.manual_seed(WSEED + 3)
     inds = torch.stack([torch.randint(jif_all.shape[1], (N, 1)).view(-1) for _ in range(K_ITERS)])
-    init_sums = [float(np.abs(O.flat_params(m)).sum()) for m in rm]
     losses, grads0 = [], None
     for i in range(K_ITERS):
         jif_current = jif_all[:, inds[i].view(-1, 1)]
@@ -134,6 +159,20 @@ def main():
         if i == 0:
             grads0 = [O.flat_grads(m) for m in rm]
         opt.step()
+        torch.set_default_dtype(torch.float64)
+        try:
+            t64 = tr64.loss_and_grads(i, inds[i]) if i == 0 else None
+            if i == 0:
+                for k_, (m_, g_) in enumerate(zip(m64, grads0)):
+                    g64 = O.flat_grads(m_)
+                    print("net %d first-step gradient: reference fp32 vs fp64 twin rel %.3g" % (k_, np.linalg.norm(g_ - g64) / np.linalg.norm(g64)))
+                tr64.opt.step()
+            else:
+                t64 = tr64.step(i, inds[i])
+        finally:
+            torch.set_default_dtype(torch.float32)
+        f64 = np.array([t64[k] for k in O.SEG_TERMS])
+        print("iter %d: reference fp32 vs fp64 twin max rel %.3g   rigidity1 %.3f" % (i, np.max(np.abs(np.array(terms) - f64) / np.maximum(np.abs(f64), 1e-12)), terms[2]))
         o_terms = tr.step(i, inds[i])
         ref_t = np.array(terms); ora_t = np.array([o_terms[k] for k in O.SEG_TERMS])
         assert np.allclose(ref_t, ora_t, rtol=2e-5, atol=1e-7), (i, ref_t, ora_t)
@@ -154,7 +193,10 @@ def main():
         grads0_samples=np.concatenate([g_[::97] for g_ in grads0]), grads0_norms=np.array([float(np.linalg.norm(g_)) for g_ in grads0]),
         end_samples=np.concatenate([e[::97] for e in ends]), psnr=ref_psnr,
         video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.mask_frames.double().sum()),
+        start_m1_sum=float(np.abs(start_m1).sum()), start_m2_sum=float(np.abs(start_m2).sum()), pre_iters=PRE_ITERS,
     )
+    # the pre-trained mapping nets the loop started from, bit-exact (fp32, 1.6 MB)
+    np.savez_compressed(os.path.join(out_dir, "seg_small_start.npz"), start_m1=start_m1, start_m2=start_m2)
     print("seg golden written; losses[0] =", losses[0], "psnr =", ref_psnr)
 
 

@@ -63,8 +63,24 @@ def _typed_config(keys, vals):
 def golden_seg():
     """Fixture of the fg/bg dual-atlas path, produced from the reference's modules by oracle/make_golden_seg.py."""
     g = dict(np.load(os.path.join(GOLDEN, "seg_small.npz"), allow_pickle=False))
+    g.update(dict(np.load(os.path.join(GOLDEN, "seg_small_start.npz"))))      # the two pre-trained mapping nets the loop starts from
     g["config"] = _typed_config(g["config_keys"], g["config_vals"])
     return g
+
+
+def seg_start_models(golden_seg):
+    """The four nets in the state the fixture's trajectory starts from: seeded init (reference construction order),
+    mapping1 / mapping2 replaced by the reference-pre-trained parameters stored in seg_small_start.npz."""
+    import torch
+    from oracle import atlas_oracle as O
+    models = O.build_seg_models(golden_seg["config"], seed=int(golden_seg["weight_seed"]))
+    for m, flat in zip(models[:2], (golden_seg["start_m1"], golden_seg["start_m2"])):
+        off = 0
+        with torch.no_grad():
+            for p in m.parameters():
+                n = p.numel(); p.copy_(torch.from_numpy(flat[off:off + n].reshape(p.shape))); off += n
+        assert off == flat.size
+    return models
 
 
 @pytest.fixture(scope="session")

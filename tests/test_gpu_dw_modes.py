@@ -1,0 +1,88 @@
+"""k_dw computes the weight gradients either on the fp32 matrix pipe (mode 0) or with fp32-faithful bf16x6 split
+operands on the bf16 matrix pipe (mode 1, the default; dw.hip).  The same forward / backward chains feed both, so the two
+reduced gradients differ only by the round-off of the contraction over the row batch: they must agree to fp32
+round-off in the regime the loop runs in (mapping nets pre-trained), at the fixture size and at BASELINE's full size,
+single and two-layer.  (From an un-pre-trained init — rigidity ~1e3, row terms cancelling to 1e-3 of their size — ANY two
+fp32 summation orders differ by ~5e-4, the reference's own fp32 gradient is 1e-3 from fp64 there: not used here.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads(af, it, inds, sds):
+    out = {}
+    for mode in (0, 1):
+        af.set_dw_mode(mode)
+        for net in af.nets:
+            af.load_state_dict(net, sds[net])
+            z = np.zeros(af.param_count(net), np.float32)
+            af.set_adam_state(net, z, z, 0)
+        af.set_debug(True)
+        losses = af.train_steps(it, 1, inds)[0]
+        out[mode] = (losses.copy(), {net: af.last_grads(net) for net in af.nets})
+    af.set_dw_mode(1)
+    return out
+
+
+@pytest.mark.parametrize("two_layer", [False, True])
+def test_dw_modes_agree_at_full_size(two_layer):
+    import aiod_amd
+    import bench
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 80
+    video = bench.synth_video_device(resx, resy, F, seed=3, device=dev)
+    if two_layer:
+        video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=3, device=dev),)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=two_layer))
+    af.upload_video(*video)
+    sds = bench.init_state_dicts(99, two_layer)
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    af.pre_train_mapping(2, seed=3)
+    if two_layer:
+        af.pre_train_mapping(2, seed=4, net=aiod_amd.NET_MAPPING2)
+    sds = {net: af.state_dict(net) for net in af.nets}
+    g = torch.Generator().manual_seed(31)
+    for it in (0, 6000):
+        inds = torch.randint(F * resx * resy, (af.N,), generator=g).numpy()
+        r = _grads(af, it, inds, sds)
+        assert np.array_equal(r[0][0], r[1][0])                          # the loss record does not depend on k_dw
+        for net in af.nets:
+            g0, g1 = r[0][1][net], r[1][1][net]
+            rel = np.linalg.norm(g1 - g0) / np.linalg.norm(g0)
+            print("two_layer", two_layer, "iter", it, "net", net, "bf16x6 vs fp32-MFMA gradient rel (L2) %.3g, max abs %.3g (|g|max %.3g)" % (rel, np.abs(g1 - g0).max(), np.abs(g0).max()))
+            assert rel < 1e-5, (it, net, rel)
+    af.close()
+    del video
+    torch.cuda.empty_cache()
+
+
+def test_dw_modes_agree_on_ragged_small_batches(golden, small_video):
+    """samples_batch 250 on an odd-sized video: segments of one and two row tiles, padded last tiles."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    cfg = dict(golden["config"]); cfg.update(samples_batch=250)
+    v = O.synthetic_video(37, 21, 5, seed=4)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg, pretrain_batch=500))
+    af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
+    m, a = O.build_single_atlas_models(cfg, seed=2)
+    af.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict()); af.load_state_dict(aiod_amd.NET_ATLAS, a.state_dict())
+    af.pre_train_mapping(40, seed=5)
+    sds = {net: af.state_dict(net) for net in af.nets}
+    off, flat = 0, af.get_params_flat(aiod_amd.NET_MAPPING1)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.from_numpy(flat[off:off + p_.numel()].reshape(p_.shape))); off += p_.numel()
+    g = torch.Generator().manual_seed(1)
+    inds = torch.randint(v.F * v.resx * v.resy, (250,), generator=g)
+    r = _grads(af, 0, inds.numpy(), sds)
+    tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    tr.loss_and_grads(0, inds)
+    for net, mdl in zip(af.nets, (m, a)):
+        g0, g1, go = r[0][1][net], r[1][1][net], O.flat_grads(mdl)
+        print("net", net, "modes rel %.3g, bf16x6 vs oracle rel %.3g" % (np.linalg.norm(g1 - g0) / np.linalg.norm(g0), np.linalg.norm(g1 - go) / np.linalg.norm(go)))
+        assert np.linalg.norm(g1 - g0) < 1e-5 * np.linalg.norm(g0)
+        assert np.linalg.norm(g1 - go) < 1e-3 * np.linalg.norm(go)
+    af.close()

@@ -78,6 +78,111 @@ def test_full_size_iteration_matches_oracle(full):
         assert (int(hip[6]), int(hip[7])) == (nf, nb)
 
 
+def _copy_params_to_oracle(af, nets, models):
+    for net, m in zip(nets, models):
+        flat, off = af.get_params_flat(net), 0
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.from_numpy(flat[off:off + p.numel()].reshape(p.shape))); off += p.numel()
+
+
+def test_full_size_trajectory_matches_oracle(full):
+    """BASELINE configs[1] at its real size, in the regime the loop actually runs in: the mapping net pre-trained on
+    the device (pre_train_mapping, unwrap_utils.py:176-198), that state copied into the CPU oracle, then TEN
+    iterations on the same injected indices straddling the global-rigidity switch (i = 4996..5005,
+    stage1_neural_atlas.py:151-231): every loss term of every iteration within BASELINE.json's 1e-3, end weights close."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    af, video, sds = full
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS)
+    for net in nets:
+        af.load_state_dict(net, sds[net])
+    af.pre_train_mapping(2, seed=11)                       # 160 Adam steps on 10 000 samples each
+    _zero_adam(af)
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video]
+    v = O.Video(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None])
+    m, a = O.build_single_atlas_models(cfg, seed=0)
+    _copy_params_to_oracle(af, nets, (m, a))
+    tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    g = torch.Generator().manual_seed(17)
+    K, first = 10, 4996
+    inds = torch.randint(v.F * v.resx * v.resy, (K, cfg["samples_batch"]), generator=g)
+    hip = af.train_steps(first, K, inds.numpy())
+    names = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+    for k in range(K):
+        t = tr.step(first + k, inds[k])
+        want = np.array([t[n] for n in names])
+        rel = np.abs(hip[k, :6] - want) / np.maximum(np.abs(want), 1e-12)
+        rel[3] = 0.0 if want[3] == 0 and hip[k, 3] == 0 else rel[3]
+        print(first + k, "rel", rel, "rigidity", want[2])
+        assert rel.max() < 1e-3, (first + k, hip[k], want)
+        assert (want[3] > 0) == (first + k <= 5000)
+    assert 2.5 < hip[0, 2] < 6.0                             # near-rigid after the pre-train (SURVEY.md Appendix D)
+    for net, mdl in zip(nets, (m, a)):
+        d = np.abs(af.get_params_flat(net) - O.flat_params(mdl))
+        print("end-weight diff net", net, "max %.3g mean %.3g" % (d.max(), d.mean()))
+        assert d.max() < 1.5e-3 and d.mean() < 3e-5        # Adam: a ~0 gradient whose sign differs moves a weight by 2*lr per step
+
+
+def test_full_size_seg_iteration_matches_oracle():
+    """BASELINE configs[4] at its real size: 80 x 768x432 + foreground masks, samples_batch 10 000, the packed
+    four-net launch plan (alpha / mapping1 / mapping2, then atlas topped up with the last alpha tiles; atlas rows
+    split at 3N between the two mapping nets' outputs).  Both mapping nets pre-trained on the device, the state copied
+    into the CPU oracle (SegAtlasTrainer), then iterations 0 and 6000 (with / without the global-rigidity rows) on
+    injected indices: all 12 loss terms within 1e-3 and the four nets' gradients against autograd through the oracle."""
+    import aiod_amd
+    import bench
+    from oracle import atlas_oracle as O
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 80
+    video = bench.synth_video_device(resx, resy, F, seed=1, device=dev)
+    fg = bench.synth_fg_mask_device(resx, resy, F, seed=1, device=dev)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=True))
+    af.upload_video(*video, fg)
+    nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_MAPPING2, aiod_amd.NET_ATLAS, aiod_amd.NET_ALPHA)
+    sds = bench.init_state_dicts(4321, two_layer=True)
+    for net in nets:
+        af.load_state_dict(net, sds[net])
+    af.pre_train_mapping(2, seed=5, net=aiod_amd.NET_MAPPING1)
+    af.pre_train_mapping(2, seed=6, net=aiod_amd.NET_MAPPING2)
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video]
+    v = O.SegVideo(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None], fg.cpu())
+    models = O.build_seg_models(cfg, seed=0)
+    _copy_params_to_oracle(af, nets, models)
+    tr = O.SegAtlasTrainer(cfg, v, models=models)
+    g = torch.Generator().manual_seed(23)
+    N = cfg["samples_batch"]
+    rows, flops = af.step_work(0)
+    assert rows == [9 * N, 6 * N, 9 * N, 5 * N]
+    af.set_debug(True)
+    for it in (0, 6000):
+        inds = torch.randint(F * resx * resy, (N,), generator=g)
+        for net, mdl in zip(nets, models):                  # same state on both sides before each comparison
+            af.load_state_dict(net, mdl.state_dict())
+            z = np.zeros(af.param_count(net), np.float32)
+            af.set_adam_state(net, z, z, 0)
+        ref = tr.loss_and_grads(it, inds)
+        hip = af.train_steps(it, 1, inds.numpy())[0]
+        want = np.array([ref[k] for k in O.SEG_TERMS])
+        rel = np.abs(hip[:12] - want) / np.maximum(np.abs(want), 1e-12)
+        print(it, "hip", hip[:12], "oracle", want, "rel", rel)
+        assert np.allclose(hip[:12], want, rtol=1e-3, atol=1e-7), (it, hip, want)
+        assert 2.5 < hip[2] < 6.0 and 2.5 < hip[3] < 6.0
+        for net, mdl in zip(nets, models):
+            gh, go = af.last_grads(net), O.flat_grads(mdl)
+            e = np.linalg.norm(gh - go) / np.linalg.norm(go)
+            print(it, "net", net, "gradient rel (L2) hip vs oracle %.3g  norm %.4g" % (e, np.linalg.norm(go)))
+            assert e < 1e-3, (it, net, e)
+        jif = tr.jif_all[:, inds]
+        nf = int((v.optical_flows_mask[jif[1], jif[0], jif[2], 0] != 0).sum()); nb = int((v.optical_flows_reverse_mask[jif[1], jif[0], jif[2], 0] != 0).sum())
+        assert (int(hip[12]), int(hip[13])) == (nf, nb)
+    af.close()
+    del video, fg
+    torch.cuda.empty_cache()
+
+
 def test_full_size_is_bit_reproducible_and_finite(full):
     import aiod_amd
     af, video, sds = full

@@ -36,8 +36,7 @@ def _terms(losses_row):
 
 def _fp64_twin(models, video, cfg):
     """fp64 copy of the oracle: the yardstick for how much fp32 round-off ANY fp32 implementation (torch's
-    included) carries on this state.  The fixture starts un-pre-trained (rigidity ~1e3, badly conditioned):
-    the reference's own fp32 trajectory drifts from fp64 by 2e-3 in the flow term within five iterations."""
+    included) carries on a given state.  Diagnostics only — no assertion depends on it."""
     import copy
     from oracle import atlas_oracle as O
     m64 = [copy.deepcopy(m).double() for m in models]
@@ -87,16 +86,20 @@ def test_forward_mapping2_and_alpha_match_reference_imlp(af, golden_seg):
 
 
 def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_seg_video):
+    """First loop iteration from the fixture's start state (both mapping nets pre-trained by the reference's
+    pre_train_mapping): all 12 loss terms and the four nets' gradients against the values the reference's own
+    modules produced (oracle/make_golden_seg.py).  Strict: 1e-4 on the terms, 1e-3 on the gradients."""
+    from conftest import seg_start_models
     from oracle import atlas_oracle as O
-    models = O.build_seg_models(golden_seg["config"], seed=int(golden_seg["weight_seed"]))
+    models = seg_start_models(golden_seg)
     _load(af, models)
     af.set_debug(True)
     inds = golden_seg["inds"][0].astype(np.int64)
     got = af.train_steps(0, 1, inds)[0]
     ref = golden_seg["losses"][0]
     assert np.allclose(_terms(got), ref, rtol=1e-4, atol=1e-7), (got, ref)
-    # gradients of the first step vs autograd through the reference's functions (fixture: strided samples + L2
-    # norms), judged against the fp64 twin: HIP may be no further from fp64 than 3x torch-fp32 is (floor 2e-4)
+    assert 2.5 < got[2] < 5.0 and 2.5 < got[3] < 5.0                  # pre-trained regime (SURVEY.md Appendix D), not ~1.3e3
+    # diagnostics only: distance of either fp32 implementation from an fp64 twin of the oracle
     tr64 = _fp64_twin(models, small_seg_video, golden_seg["config"])
     with _f64():
         tr64.loss_and_grads(0, torch.from_numpy(inds))
@@ -111,33 +114,36 @@ def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_s
         s64 = g64s[k][::97]
         e_hip = np.linalg.norm(g[::97] - s64) / np.linalg.norm(s64)
         e_ref = np.linalg.norm(ref_s - s64) / np.linalg.norm(s64)
-        print("net", k, "grad error vs fp64: hip %.3g  reference-fp32 %.3g  hip-vs-reference %.3g" % (e_hip, e_ref, np.linalg.norm(g[::97] - ref_s) / np.linalg.norm(s64)))
-        assert e_hip < max(3 * e_ref, 2e-4), (k, e_hip, e_ref)
+        e_hr = np.linalg.norm(g[::97] - ref_s) / np.linalg.norm(ref_s)
+        print("net", k, "grad error vs fp64: hip %.3g  reference-fp32 %.3g  hip-vs-reference %.3g" % (e_hip, e_ref, e_hr))
+        assert e_hr < 1e-3, (k, e_hr, e_hip, e_ref)
 
 
 def test_trajectory_psnr_and_parameters_match_reference(af, golden_seg, small_seg_video):
+    """Ten iterations from the reference's post-pre-train state on the reference's index stream (global rigidity
+    switches off after iteration 5, bootstrapping after 7): EVERY term of EVERY iteration within BASELINE.json's
+    1e-3 of the reference's fp32 trajectory, end weights close, PSNR within 0.1 dB."""
+    from conftest import seg_start_models
     from oracle import atlas_oracle as O
-    models = O.build_seg_models(golden_seg["config"], seed=int(golden_seg["weight_seed"]))
+    models = seg_start_models(golden_seg)
     _load(af, models)
     inds = golden_seg["inds"].astype(np.int64)
     got = af.train_steps(0, inds.shape[0], inds)
     tr64 = _fp64_twin(models, small_seg_video, golden_seg["config"])
-    for i in range(inds.shape[0]):      # global rigidity switches off after iteration 5, bootstrapping after 7
+    for i in range(inds.shape[0]):
         with _f64():
             t = tr64.step(i, torch.from_numpy(inds[i]))
         f64 = np.array([t[k] for k in O.SEG_TERMS])
         ref = golden_seg["losses"][i]
         den = np.maximum(np.abs(f64), 1e-12)
         e_hip, e_ref = np.abs(_terms(got[i]) - f64) / den, np.abs(ref - f64) / den
-        print(i, "max rel error vs fp64: hip %.3g  reference-fp32 %.3g" % (e_hip.max(), e_ref.max()))
-        # within 1e-3 of the reference's fp32 trajectory, or no further from fp64 than 3x the reference itself is
-        ok = (np.abs(_terms(got[i]) - ref) <= 1e-3 * np.abs(ref) + 1e-6) | (e_hip <= 3 * e_ref)
-        assert ok.all(), (i, got[i], ref, f64)
-        if i < 3:
-            assert np.allclose(_terms(got[i]), ref, rtol=1e-3, atol=1e-6), (i, got[i], ref)
+        e_hr = np.abs(_terms(got[i]) - ref) / np.maximum(np.abs(ref), 1e-12)
+        print(i, "max rel: hip-vs-reference %.3g (term %d) | vs fp64: hip %.3g  reference-fp32 %.3g" % (e_hr.max(), int(e_hr.argmax()), e_hip.max(), e_ref.max()))
+        assert np.allclose(_terms(got[i]), ref, rtol=1e-3, atol=1e-6), (i, got[i], ref)
     ends = np.concatenate([af.get_params_flat(net)[::97] for net in _nets()])
     d = np.abs(ends - golden_seg["end_samples"])   # ten Adam steps of lr 1e-4: a ~0 gradient whose sign differs moves a weight by 2*lr per step
-    assert d.max() < 1e-3 and d.mean() < 1e-5, (d.max(), d.mean())
+    print("end-weight diff max %.3g mean %.3g" % (d.max(), d.mean()))
+    assert d.max() < 1e-3 and d.mean() < 3e-5, (d.max(), d.mean())
     mean, per = af.psnr()
     assert abs(mean - float(golden_seg["psnr"])) < 0.1, (mean, float(golden_seg["psnr"]))
     rgb, sse = af.render_frame(2)

@@ -104,7 +104,10 @@ def test_alpha_pe_layout():
 
 
 def test_seg_trajectory_matches_reference_fixture(golden_seg, small_seg_video):
-    tr = O.SegAtlasTrainer(golden_seg["config"], small_seg_video, seed=int(golden_seg["weight_seed"]))
+    from conftest import seg_start_models
+    tr = O.SegAtlasTrainer(golden_seg["config"], small_seg_video, models=seg_start_models(golden_seg))
+    assert abs(float(np.abs(O.flat_params(tr.m1)).sum()) - float(golden_seg["start_m1_sum"])) < 1e-3
+    assert 2.5 < float(golden_seg["losses"][0][2]) < 5.0 and 2.5 < float(golden_seg["losses"][0][3]) < 5.0    # pre-trained: J ~ identity
     inds = torch.from_numpy(golden_seg["inds"].astype(np.int64))
     for i in range(inds.shape[0]):
         t = tr.step(i, inds[i])

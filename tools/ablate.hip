@@ -9,6 +9,36 @@
 #include "../all-in-one-deflicker_amd/csrc/mlp.hip"
 #include "../all-in-one-deflicker_amd/csrc/mlp16.hip"
 
+// Ceiling probe: a pure v_mfma_f32_32x32x2_f32 stream in the geometry of the chains — 256 threads,
+// one wave per SIMD (launch_bounds(256,1) + 128 KB of dynamic LDS so no second workgroup co-resides), 8 independent
+// accumulators, operands in VGPRs, no LDS / VMEM traffic inside the loop.  FLOPs = 2*32*32*2 per MFMA per wave.
+__global__ __launch_bounds__(256, 1) void k_mfma_ceiling(float* out, int iters, float seed) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  f32x16 acc[8];
+#pragma unroll
+  for (int T = 0; T < 8; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
+  float a[8], b[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = seed * (float)(threadIdx.x + i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = seed + (float)i;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int T = 0; T < 8; ++T) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[T], b[p], acc[T], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int T = 0; T < 8; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[T][r];
+  if (s == 12345.678f) out[threadIdx.x] = s + smem_c[0];
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -30,6 +60,22 @@ int main(int argc, char** argv) {
   BwdArgs ba{}; ba.wimg = img; ba.out = out; ba.dout = in; ba.masks = masks; ba.dz = dz; ba.dz_last = dzl;
   ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (argc > 2 && atoi(argv[2]) == 1) {     // ablate <NT> 1: the pure-MFMA ceiling
+    CK(hipFuncSetAttribute((const void*)k_mfma_ceiling, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    for (int wgs : {256, 512, 704}) {
+      const int iters = 160;                // 160 x 32 = 5120 MFMAs per wave ~ one mapping chain
+      for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_mfma_ceiling, dim3(wgs), dim3(256), 131072, 0, out, iters, 0.f);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_mfma_ceiling, dim3(wgs), dim3(256), 131072, 0, out, iters, 0.f);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      const double fl = (double)wgs * 4 * iters * 32 * 4096.0;
+      printf("mfma_ceiling wgs=%d: %.4f ms  %.1f TF (%.1f%% of 157.3; %.1f%% counting whole rounds of 256 CUs)\n", wgs, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100,
+             (double)((wgs + 255) / 256 * 256) * 4 * iters * 32 * 4096.0 / ms / 1e9 / 157.3 * 100);
+    }
+    return 0;
+  }
   const char* names[4] = {"fwd_map32", "bwd_map32", "fwd_map16", "bwd_map16"};
   for (int which = 0; which < 4; ++which) {
     auto go = [&]() {

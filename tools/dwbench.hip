@@ -1,0 +1,39 @@
+// tools/dwbench.hip — k_dw micro-harness (not product code): one 8x8 job, every workgroup one segment of NT/256 row tiles.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDW_ABL=<bits> tools/dwbench.hip -o tools/bin/dwb_<bits>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../all-in-one-deflicker_amd/csrc/dw.hip"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+int main(int argc, char** argv) {
+  const int per = argc > 1 ? atoi(argv[1]) : 66;       // row tiles per workgroup
+  const int nwg = 256, NT = per * nwg, reps = 10;
+  af_dw_init();
+  float *A, *B, *partial;
+  CK(hipMalloc(&A, (size_t)NT * AF_TILE_F * 4)); CK(hipMalloc(&B, (size_t)NT * AF_TILE_F * 4));
+  CK(hipMalloc(&partial, (size_t)nwg * (65536 + 256) * 4));
+  std::vector<float> h((size_t)1 << 22); for (auto& x : h) x = rand() / (float)RAND_MAX - 0.5f;
+  for (size_t off = 0; off < (size_t)NT * AF_TILE_F; off += h.size()) {
+    const size_t n = std::min(h.size(), (size_t)NT * AF_TILE_F - off);
+    CK(hipMemcpy(A + off, h.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B + off, h.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  DwJob j{}; j.A = A; j.B = B; j.a_stride = AF_TILE_F; j.b_stride = AF_TILE_F; j.shape = DW_8x8; j.part_off = 0; j.part_blk = 65536 + 256;
+  std::vector<DwSeg> segs((size_t)nwg * DW_MAXSEG, DwSeg{-1, 0, 0, 0});
+  for (int w = 0; w < nwg; ++w) segs[(size_t)w * DW_MAXSEG] = DwSeg{0, w * per, (w + 1) * per, w};
+  DwJob* dj; DwSeg* ds; CK(hipMalloc(&dj, sizeof j)); CK(hipMalloc(&ds, segs.size() * sizeof(DwSeg)));
+  CK(hipMemcpy(dj, &j, sizeof j, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, segs.data(), segs.size() * sizeof(DwSeg), hipMemcpyHostToDevice));
+  DwArgs a{dj, ds, partial, nullptr};
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 2; ++mode) {
+    for (int r = 0; r < 2; ++r) af_launch_dw(&a, nwg, mode, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) af_launch_dw(&a, nwg, mode, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double fl = (double)NT * 32 * 2.0 * 256 * 256, by = (double)NT * 2 * AF_TILE_F * 4;
+    printf("DW_ABL=%d mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, mode, mode ? "bf16x6" : "fp32 MFMA", per, ms, fl / ms / 1e9, by / ms / 1e9);
+  }
+  return 0;
+}
