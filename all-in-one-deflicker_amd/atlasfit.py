@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
-    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_set_dw_mode",
+    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_set_dw_mode", "af_set_mlp_mode",
 ]
 
 
@@ -169,6 +169,7 @@ def load_library(path=None):
         "af_flow_consistency": (i32, [i32, vp, vp, i32, i32, vp, i64, i64, C.c_float, i32]),
         "af_debug_dw_clocks": (i32, [vp, i32, vp, i32]),
         "af_set_dw_mode": (i32, [vp, i32]),
+        "af_set_mlp_mode": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -187,26 +188,37 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-# layer shapes of the IMLPs (stage1_neural_atlas.py:112-128; stage1_neural_atlas_seg.py:127-161)
-def imlp_shapes(net, pe_atlas=10, pe_alpha=5):
-    if net == NET_MAPPING1:
-        dims = [(256, 3)] + [(256, 256)] * 4 + [(2, 256)]
-    elif net == NET_MAPPING2:
-        dims = [(256, 3)] + [(256, 256)] * 2 + [(2, 256)]
-    elif net == NET_ATLAS:
-        e = 4 * pe_atlas
-        dims = [(256, e), (256, 256), (256, 256), (256, 256), (256, 256 + e), (256, 256), (256, 256), (3, 256 + e)]
-    elif net == NET_ALPHA:
-        dims = [(256, 6 * pe_alpha)] + [(256, 256)] * 6 + [(1, 256)]
-    else:
+# layer shapes of the IMLPs (stage1_neural_atlas.py:112-128; stage1_neural_atlas_seg.py:127-161; IMLP.__init__,
+# implicit_neural_networks.py:16-60: skip layers [4, 7] on the atlas net only)
+def imlp_shapes(net, cfg=None, pe_atlas=10, pe_alpha=5):
+    """[(out_features, in_features)] per layer.  With `cfg` (an AfConfig) the widths / depths / PE sizes come from it —
+    AtlasFit.__init__ checks the result against the library's own parameter count, so a config the library cannot run
+    fails loudly in Python, before anything reaches the C side."""
+    hid = {NET_MAPPING1: 256, NET_MAPPING2: 256, NET_ATLAS: 256, NET_ALPHA: 256}
+    nl = {NET_MAPPING1: 6, NET_MAPPING2: 4, NET_ATLAS: 8, NET_ALPHA: 8}
+    if cfg is not None:
+        hid = {NET_MAPPING1: cfg.number_of_channels_mapping1, NET_MAPPING2: cfg.number_of_channels_mapping2,
+               NET_ATLAS: cfg.number_of_channels_atlas, NET_ALPHA: cfg.number_of_channels_alpha}
+        nl = {NET_MAPPING1: cfg.number_of_layers_mapping1, NET_MAPPING2: cfg.number_of_layers_mapping2,
+              NET_ATLAS: cfg.number_of_layers_atlas, NET_ALPHA: cfg.number_of_layers_alpha}
+        pe_atlas, pe_alpha = cfg.positional_encoding_num_atlas, cfg.positional_encoding_num_alpha
+    if net not in hid:
         raise ValueError("net")
+    h, L = int(hid[net]), int(nl[net])
+    enc = {NET_MAPPING1: 3, NET_MAPPING2: 3, NET_ATLAS: 4 * pe_atlas, NET_ALPHA: 6 * pe_alpha}[net]
+    out = {NET_MAPPING1: 2, NET_MAPPING2: 2, NET_ATLAS: 3, NET_ALPHA: 1}[net]
+    skips = (4, 7) if net == NET_ATLAS else ()
+    dims = []
+    for i in range(L):
+        fan_in = enc if i == 0 else (h + enc if i in skips else h)
+        dims.append((out if i == L - 1 else h, fan_in))
     return dims
 
 
-def flatten_state_dict(sd, net):
+def flatten_state_dict(sd, net, cfg=None):
     """IMLP.state_dict() (torch tensors or arrays) -> flat fp32 vector in state_dict order."""
     parts = []
-    for i, (o, k) in enumerate(imlp_shapes(net)):
+    for i, (o, k) in enumerate(imlp_shapes(net, cfg)):
         w = np.asarray(sd["hidden.%d.weight" % i].detach().cpu().numpy() if hasattr(sd["hidden.%d.weight" % i], "detach") else sd["hidden.%d.weight" % i], dtype=np.float32)
         b = np.asarray(sd["hidden.%d.bias" % i].detach().cpu().numpy() if hasattr(sd["hidden.%d.bias" % i], "detach") else sd["hidden.%d.bias" % i], dtype=np.float32)
         assert w.shape == (o, k) and b.shape == (o,), (i, w.shape, b.shape)
@@ -214,9 +226,9 @@ def flatten_state_dict(sd, net):
     return np.concatenate(parts)
 
 
-def unflatten_state_dict(flat, net):
+def unflatten_state_dict(flat, net, cfg=None):
     out, off = {}, 0
-    for i, (o, k) in enumerate(imlp_shapes(net)):
+    for i, (o, k) in enumerate(imlp_shapes(net, cfg)):
         out["hidden.%d.weight" % i] = flat[off:off + o * k].reshape(o, k).copy(); off += o * k
         out["hidden.%d.bias" % i] = flat[off:off + o].copy(); off += o
     assert off == flat.size
@@ -275,6 +287,11 @@ class AtlasFit:
         self.two_layer = bool(cfg.two_layer)
         self.nets = (NET_MAPPING1, NET_MAPPING2, NET_ATLAS, NET_ALPHA) if self.two_layer else (NET_MAPPING1, NET_ATLAS)
         self.loss_width = int(self.lib.af_loss_width(h))
+        for net in self.nets:                       # the Python view of the architecture must be the library's
+            n = sum(o * k + o for o, k in imlp_shapes(net, cfg))
+            if n != self.param_count(net):
+                self.close()
+                raise AtlasFitError(-1, "net %d: config describes %d parameters, libatlasfit.so built %d" % (net, n, self.param_count(net)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -317,13 +334,13 @@ class AtlasFit:
         return int(self.lib.af_param_count(self.h, net))
 
     def load_state_dict(self, net, sd):
-        flat = flatten_state_dict(sd, net)
+        flat = flatten_state_dict(sd, net, self.cfg)
         self._chk(self.lib.af_set_params(self.h, net, _ptr(flat), flat.size))
 
     def state_dict(self, net):
         flat = np.empty(self.param_count(net), np.float32)
         self._chk(self.lib.af_get_params(self.h, net, _ptr(flat), flat.size))
-        return unflatten_state_dict(flat, net)
+        return unflatten_state_dict(flat, net, self.cfg)
 
     def get_params_flat(self, net):
         flat = np.empty(self.param_count(net), np.float32)
@@ -398,6 +415,10 @@ class AtlasFit:
     def set_dw_mode(self, mode):
         """k_dw arithmetic: 1 = bf16x6 split operands on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check)."""
         self._chk(self.lib.af_set_dw_mode(self.h, int(mode)))
+
+    def set_mlp_mode(self, mode):
+        """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check)."""
+        self._chk(self.lib.af_set_mlp_mode(self.h, int(mode)))
 
     def set_debug(self, on=True):
         self._chk(self.lib.af_set_debug(self.h, int(on)))

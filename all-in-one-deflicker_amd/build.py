@@ -5,8 +5,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libatlasfit.so")
-UNITS = ["mlp.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
-HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", os.path.join("..", "..", "include", "atlasfit.h")]
+UNITS = ["mlp.hip", "mlpbf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
+HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", os.path.join("..", "..", "include", "atlasfit.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -178,35 +178,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 // per 256x256 layer, read once).
 // One stage of the LDS ring (16 rows) is exactly one k-step: lane (m, h) holds rows 8h..8h+7 of feature m — two
 // ds_read_b128 of the T-layout half tile per operand tile.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct DwSplit { u32x4 h, m, l; };
-AF_DEV uint32_t dw_pk(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }   // v_cvt_pk_bf16_f32 (RNE)
-AF_DEV float dw_sub(float a, float b) {
-  if constexpr (DW_ABL & 8) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // keeps hipcc from SLP-packing into v_pk_add_f32
-  return a - b;
-}
-AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
-  DwSplit s;
-  if constexpr (DW_ABL & 1) {
-    s.h = __builtin_bit_cast(u32x4, lo4); s.m = __builtin_bit_cast(u32x4, hi4); s.l = s.h;
-    return s;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = i < 2 ? lo4[2 * i] : hi4[2 * i - 4], b = i < 2 ? lo4[2 * i + 1] : hi4[2 * i - 3];
-    const uint32_t h = dw_pk(a, b);
-    const float ra = dw_sub(a, __builtin_bit_cast(float, h << 16)), rb = dw_sub(b, __builtin_bit_cast(float, h & 0xffff0000u));
-    const uint32_t m = dw_pk(ra, rb);
-    const float qa = dw_sub(ra, __builtin_bit_cast(float, m << 16)), qb = dw_sub(rb, __builtin_bit_cast(float, m & 0xffff0000u));
-    s.h[i] = h; s.m[i] = m; s.l[i] = dw_pk(qa, qb);
-  }
-  return s;
-}
-AF_DEV f32x16 dw_mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
+#include "bfsplit.h"
 
 template <int TO, int TI, int TOW, int TIW>
 AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,

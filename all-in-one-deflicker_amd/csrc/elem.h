@@ -96,12 +96,18 @@ struct AdamJob {
   uint32_t bias_img_off;// float offset in the padded bias array
   uint32_t pe_kind;     // column -> slot permutation for columns >= hid_cols (0/1 identity, 2 alpha)
   uint32_t hid_cols;    // leading identity-mapped columns of the LAYER (256 for skip layers, 0 for PE first layers, p_ld otherwise)
+  // weight streams of the bf16x6 chains (mlpbf.hip): byte offset of the block this job writes, its kind (0 = fp32 block packed like
+  // the fp32 images with row padding *_mpad and reduction index k - sf_k0; 1 = 256x256 block as three bf16 images), -1 = none
+  int32_t  sf_off; uint32_t sf_kind, sf_mpad, sf_k0;
+  int32_t  sb_off; uint32_t sb_kind, sb_mpad;
 };
 struct AdamHyper { float step_size, bc2_sqrt, one_minus_b1, beta2, one_minus_b2, eps; };
-struct AdamBufs { float* params; float* m; float* v; float* img_f; float* img_b; float* bias_img; };
+struct AdamBufs { float* params; float* m; float* v; float* img_f; float* img_b; float* bias_img; char* sf; char* sb; };
 struct AdamArgs {
   const AdamJob* jobs; const float* partial;
   AdamBufs bufs; AdamHyper hy;
   float* grad_out;           // optional: reduced gradient in flat param order (tests)
   const float* loss_part; float* loss_out; int* counts; int loss_nblk;
+  int* nan_flag;             // set to 1 when a parameter is not finite, a folded loss term is NaN, or (check_counts) a flow-match set is empty
+  int check_counts;
 };

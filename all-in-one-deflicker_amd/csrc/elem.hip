@@ -59,33 +59,53 @@ __global__ void k_pack_table(PackArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Input builder kernels (one thread per destination pixel; fp64 interpolation like the numpy/cv2 double path).
+// Input builder kernels (one thread per destination pixel), in OpenCV's arithmetic (published algorithm of
+// imgproc/resize.cpp and imgwarp.cpp; the tests hold an independent CPU restatement with hand-computed vectors):
+//  * cv2.resize INTER_LINEAR: per axis  f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s (float), taps clamp at the
+//    edges with weight 1; the two coefficients are the floats 1.f - f and f (alpha type float even for CV_64F images);
+//    horizontal pass, then vertical, in double for CV_64F sources (8-bit frames / masks: `astype(float64) / 255`,
+//    unwrap_utils.py:128,68) and in float for CV_32F sources (flows, :35);
+//  * cv2.remap INTER_LINEAR on a CV_32FC2 map (:22): position -> fixed point with INTER_BITS = 5 (cvRound(x * 32), round
+//    half to even), i.e. quantised to 1/32 px; table weights (1-fy)(1-fx) ...; float accumulation left to right;
+//    constant-0 border tap by tap.
+template <class WT>
+AF_DEV float resize_tap(const ResizeArgs& a, int y0, int y1, int x0, int x1, float a0, float a1, float b0, float b1, int c) {
+#pragma clang fp contract(off)
+  auto tap = [&](int yy, int xx) -> WT {
+    const size_t i = ((size_t)yy * a.sw + xx) * a.ch + c;
+    return a.src_u8 ? (WT)((double)((const unsigned char*)a.src)[i] / 255.0) : (WT)((const float*)a.src)[i];
+  };
+  const WT t0 = tap(y0, x0) * (WT)a0 + tap(y0, x1) * (WT)a1;
+  const WT t1 = tap(y1, x0) * (WT)a0 + tap(y1, x1) * (WT)a1;
+  return (float)(t0 * (WT)b0 + t1 * (WT)b1);
+}
+AF_DEV void resize_coeff(int d, int src, int dst, int& s0, int& s1, float& c0, float& c1) {
+#pragma clang fp contract(off)
+  const double scale = (double)src / (double)dst;
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= src - 1) { s = src - 1; f = 0.f; }
+  s0 = s; s1 = min(s + 1, src - 1); c0 = 1.f - f; c1 = f;
+}
 __global__ void k_resize_bilinear(ResizeArgs a) {
-#pragma clang fp contract(off)      // same roundings as the host restatement (no FMA contraction)
+#pragma clang fp contract(off)      // same roundings as the restatements (no FMA contraction)
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)a.dh * a.dw) return;
   const int y = (int)(idx / a.dw), x = (int)(idx - (long long)y * a.dw);
-  const double sx = (double)a.sw / a.dw, sy = (double)a.sh / a.dh;
-  const double fx = ((double)x + 0.5) * sx - 0.5, fy = ((double)y + 0.5) * sy - 0.5;
-  const double x0f = floor(fx), y0f = floor(fy);
-  const double ax = fx - x0f, ay = fy - y0f;
-  const int x0 = (int)x0f, y0 = (int)y0f;
-  const int x0c = min(max(x0, 0), a.sw - 1), x1c = min(max(x0 + 1, 0), a.sw - 1);
-  const int y0c = min(max(y0, 0), a.sh - 1), y1c = min(max(y0 + 1, 0), a.sh - 1);
+  const bool same = a.sh == a.dh && a.sw == a.dw;          // identity: cv::resize copies
+  int x0, x1, y0, y1; float a0, a1, b0, b1;
+  resize_coeff(x, a.sw, a.dw, x0, x1, a0, a1);
+  resize_coeff(y, a.sh, a.dh, y0, y1, b0, b1);
   for (int c = 0; c < a.ch; ++c) {
-    auto tap = [&](int yy, int xx) -> double {
-      const size_t i = ((size_t)yy * a.sw + xx) * a.ch + c;
-      return a.src_u8 ? (double)((const unsigned char*)a.src)[i] / 255.0 : (double)((const float*)a.src)[i];
-    };
-    const bool same = a.sh == a.dh && a.sw == a.dw;        // identity: the reference copies (no interpolation round-off)
-    double v;
-    if (same) v = tap(y, x);
-    else {
-      const double top = tap(y0c, x0c) * (1.0 - ax) + tap(y0c, x1c) * ax;
-      const double bot = tap(y1c, x0c) * (1.0 - ax) + tap(y1c, x1c) * ax;
-      v = top * (1.0 - ay) + bot * ay;
+    float o;
+    if (same) {
+      const size_t i = ((size_t)y * a.sw + x) * a.ch + c;
+      o = a.src_u8 ? (float)((double)((const unsigned char*)a.src)[i] / 255.0) : ((const float*)a.src)[i];
+    } else {
+      o = a.src_u8 ? resize_tap<double>(a, y0, y1, x0, x1, a0, a1, b0, b1, c) : resize_tap<float>(a, y0, y1, x0, x1, a0, a1, b0, b1, c);
     }
-    float o = (float)v;
     if (c == 0) o = o * (float)a.scale0; else if (c == 1) o = o * (float)a.scale1;     // fp32, like `flow[:, :, c] *= s`
     a.dst[idx * a.pix_stride + (long long)c * a.ch_stride + a.offset] = o;
   }
@@ -97,16 +117,17 @@ __global__ void k_flow_consistency(ConsistencyArgs a) {
   if (idx >= (long long)a.h * a.w) return;
   const int y = (int)(idx / a.w), x = (int)(idx - (long long)y * a.w);
   const float u = a.f12[idx * 2], v = a.f12[idx * 2 + 1];
-  const float mx = u + (float)x, my = v + (float)y;                      // sampling position in the other frame
-  const float x0f = floorf(mx), y0f = floorf(my);
-  const long long x0 = (long long)x0f, y0 = (long long)y0f;
-  const float fx = mx - x0f, fy = my - y0f;
+  const float mx = u + (float)x, my = v + (float)y;                      // sampling position in the other frame (`flow += arange`)
+  const long long qx = (long long)rintf(mx * 32.f), qy = (long long)rintf(my * 32.f);   // cvRound(pos * INTER_TAB_SIZE), half to even
+  const long long x0 = qx >> 5, y0 = qy >> 5;
+  const float fx = (float)(qx & 31) / 32.f, fy = (float)(qy & 31) / 32.f;
+  const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
   float acc[2];
   for (int c = 0; c < 2; ++c) {
     auto tap = [&](long long yy, long long xx) -> float {              // constant-0 border (cv2.remap default)
       return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? a.f21[(yy * a.w + xx) * 2 + c] : 0.f;
     };
-    acc[c] = tap(y0, x0) * (1.f - fx) * (1.f - fy) + tap(y0, x0 + 1) * fx * (1.f - fy) + tap(y0 + 1, x0) * (1.f - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy;
+    acc[c] = ((tap(y0, x0) * w0 + tap(y0, x0 + 1) * w1) + tap(y0 + 1, x0) * w2) + tap(y0 + 1, x0 + 1) * w3;
   }
   const float du = u + acc[0], dv = v + acc[1];
   const float nrm = sqrtf(du * du + dv * dv);
@@ -486,6 +507,27 @@ __global__ __launch_bounds__(256) void k_pre_loss(PreLossArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Split-K reduction + Adam (torch.optim.Adam defaults, stage1_neural_atlas.py:132-134,231) + re-emission
 // of the three weight views the GEMM kernels read (canonical, forward image, backward image).
+// One weight into a 256x256 bf16x3 block of a chain stream (layout: mlpbf.hip header): element (m, k) of the product's A
+// matrix goes, as its three bf16 levels hi / mid / lo (round-to-nearest-even, exact fp32 residuals — bfsplit.h), to
+// byte ((((s*8 + m/32)*3 + level)*2 + h)*32 + m%32)*16 + 2 i  with k = 32T + 8q + 4h + p,  s = 2T + q/2,  i = 4(q%2) + p.
+AF_DEV uint16_t bf16_rne(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);          // finite inputs (parameters are checked finite below)
+}
+AF_DEV void emit_bf3(char* block, uint32_t m, uint32_t k, float p) {
+  const uint32_t T = k >> 5, q = (k >> 3) & 3, hh = (k >> 2) & 1, pp = k & 3;
+  const uint32_t s = 2 * T + (q >> 1), i = 4 * (q & 1) + pp;
+  const uint16_t h = bf16_rne(p);
+  const float r1 = p - __builtin_bit_cast(float, (uint32_t)h << 16);
+  const uint16_t mi = bf16_rne(r1);
+  const float r2 = r1 - __builtin_bit_cast(float, (uint32_t)mi << 16);
+  const uint16_t lo = bf16_rne(r2);
+  const size_t base = ((size_t)((s * 8 + (m >> 5)) * 3) * 2 + hh) * 32 * 16 + (size_t)(m & 31) * 16 + i * 2;
+  *(uint16_t*)(block + base) = h;
+  *(uint16_t*)(block + base + 1024) = mi;
+  *(uint16_t*)(block + base + 2048) = lo;
+}
+
 AF_DEV void emit_weight(const AdamJob& j, const AdamBufs& b, uint32_t o, uint32_t i, float p) {
   const uint32_t col = j.col0 + i;
   uint32_t k = col;
@@ -495,6 +537,14 @@ AF_DEV void emit_weight(const AdamJob& j, const AdamBufs& b, uint32_t o, uint32_
     // W^T image: m = in feature (PE slot order for a PE first layer), k = out feature
     const uint32_t mrow = j.hid_cols ? col : (uint32_t)af_pe_slot_of_feature((int)j.pe_kind, (int)col);
     b.img_b[(uint32_t)j.b_img_off + af_img_index(j.b_mpad, mrow, o)] = p;
+    if (b.sb && j.sb_off >= 0) {
+      if (j.sb_kind == 0) ((float*)(b.sb + j.sb_off))[af_img_index(j.sb_mpad, mrow, o)] = p;
+      else                emit_bf3(b.sb + j.sb_off, mrow, o, p);
+    }
+  }
+  if (b.sf && j.sf_off >= 0) {
+    if (j.sf_kind == 0) ((float*)(b.sf + j.sf_off))[af_img_index(j.sf_mpad, o, k - j.sf_k0)] = p;
+    else                emit_bf3(b.sf + j.sf_off, o, k, p);
   }
 }
 
@@ -522,6 +572,9 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
       a.bufs.m[pidx] = m; a.bufs.v[pidx] = v; a.bufs.params[pidx] = p;
       if (a.grad_out) a.grad_out[pidx] = g;
     }
+    // torch's relu / Linear carry a NaN or inf parameter into the loss; v_max_f32 (af_relu) would drop a NaN pre-activation
+    // silently, so the condition is raised here instead (Adam's steps are bounded by lr: activations cannot overflow otherwise)
+    if (a.nan_flag && !(fabsf(p) <= 3.4028235e38f)) *a.nan_flag = 1;
     if (is_bias) a.bufs.bias_img[j.bias_img_off + o] = p;
     else emit_weight(j, a.bufs, o, i, p);
   }
@@ -531,8 +584,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
       float s = 0.f;
       for (int b = 0; b < a.loss_nblk; ++b) s += a.loss_part[b * AF_LOSS_W + threadIdx.x];
       a.loss_out[threadIdx.x] = s;
+      if (a.nan_flag && !(s == s)) *a.nan_flag = 1;
     } else if (threadIdx.x < AF_LOSS_W) {
       a.loss_out[threadIdx.x] = (float)a.counts[threadIdx.x - (AF_LOSS_W - 2)];
+      if (a.nan_flag && a.check_counts && a.counts[threadIdx.x - (AF_LOSS_W - 2)] == 0) *a.nan_flag = 1;     // mean over an empty set (loss_utils.py:317-320)
       a.counts[threadIdx.x - (AF_LOSS_W - 2)] = 0;
     }
   }

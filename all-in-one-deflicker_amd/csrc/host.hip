@@ -24,6 +24,10 @@ int af_launch_fwd16(int net, const FwdArgs* a, hipStream_t s);
 int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s);
 int af_mlp16_init();
 int af_mlp_chunk_bytes(int net, int which);
+int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s);
+int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s);
+int af_mlp_bf_init();
+int af_mlp_chunk_bytes_bf(int net, int which);
 int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s);
 int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
@@ -43,7 +47,7 @@ int af_launch_frame_finish(const float* out_atlas, const float* table, float* rg
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;     // handle-less errors (af_create, the input-builder utilities): per calling thread
 
 struct NetDesc {
   int id = -1, NL = 0, in_kind = 0, in_feat0 = 0, out = 0, pe_feats = 0, pe_kind = 0;
@@ -56,6 +60,10 @@ struct NetDesc {
   long long b_off_img[AF_MAX_LAYERS]; int b_mpad[AF_MAX_LAYERS];
   size_t f_base = 0, b_base = 0, bias_base = 0;        // float offsets of this net's region (chunk offsets are relative to these)
   std::vector<AfChunk> fchunks, bchunks;               // the planned chunk sequences (checked against the kernels' ChunkBytes)
+  // weight streams of the bf16x6 chains (mlpbf.hip): byte offsets of this net's stream in the stream buffers and, per layer,
+  // of its 256x256 bf16x3 block (-1: none) and of its fp32 block (layer 0 / skip columns / output layer; -1: none)
+  size_t sf_base = 0, sb_base = 0;
+  long long sf_hid[AF_MAX_LAYERS], sf_fp[AF_MAX_LAYERS], sb_hid[AF_MAX_LAYERS], sb_fp[AF_MAX_LAYERS];
   // activations
   int nt_cap = 0;
   float *coords = nullptr, *x0_tile = nullptr;         // input rows [rows_pad][4] (+ T-layout copy for the layer-0 dW of xyt nets)
@@ -79,7 +87,9 @@ struct af_handle {
   int device = 0; hipStream_t stream = nullptr; int ncu = 256;
   std::string err;
   NetDesc nets[AF_MAX_NETS];
-  size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0;
+  size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0, sf_bytes = 0, sb_bytes = 0;
+  char *img_sf = nullptr, *img_sb = nullptr;   // bf16x6 chain streams
+  int mlp_mode = 1;                            // MLP chains: 1 = hidden layers on the bf16 matrix pipe, fp32-faithful bf16x6 (mlpbf.hip); 0 = fp32 MFMA (mlp.hip)
   float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *pre_m = nullptr, *pre_v = nullptr, *grads = nullptr;
   float *img_f = nullptr, *img_b = nullptr, *bias_img = nullptr;
   long long adam_step = 0;
@@ -89,6 +99,7 @@ struct af_handle {
   int N = 0;
   float *samples = nullptr, *loss_part = nullptr, *loss_log = nullptr;
   int* counts = nullptr; int loss_nblk_cap = 0; size_t loss_log_cap = 0;
+  int* nan_flag = nullptr;                    // sticky, set on the device by k_adam: a non-finite parameter, a NaN loss term or an empty flow-match set
   int cur_nseg = 0;
   // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
   Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
@@ -176,6 +187,31 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
   b_cursor += boff / 4;
 }
 
+// Streams of the bf16x6 chains: fp32 blocks for layer 0, the skip columns and the output layers, eight 48 KB bf16x3 chunks
+// per 256x256 hidden product, in consumption order (mlpbf.hip).  Returns false if the sizes disagree with the kernels'.
+bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
+  const int peg = (n.pe_feats + 7) / 8;
+  const int cb_l0 = af_mlp_chunk_bytes_bf(n.id, 0), cb_hid = af_mlp_chunk_bytes_bf(n.id, 1), cb_skip = af_mlp_chunk_bytes_bf(n.id, 2);
+  const int cb_last = af_mlp_chunk_bytes_bf(n.id, 3), cb_blast = af_mlp_chunk_bytes_bf(n.id, 4), cb_bl0h = af_mlp_chunk_bytes_bf(n.id, 5);
+  for (int l = 0; l < AF_MAX_LAYERS; ++l) n.sf_hid[l] = n.sf_fp[l] = n.sb_hid[l] = n.sb_fp[l] = -1;
+  n.sf_base = f_cursor; n.sb_base = b_cursor;
+  size_t off = 0;
+  n.sf_fp[0] = (long long)off; off += cb_l0;
+  if ((size_t)cb_l0 < round_up((size_t)(n.in_kind == AF_IN_XYT ? 1 : peg) * 2 * AF_HID * 16, 4096)) return false;
+  for (int l = 1; l < n.NL - 1; ++l) {
+    n.sf_hid[l] = (long long)off; off += (size_t)8 * cb_hid;
+    if ((n.skip >> l) & 1) { n.sf_fp[l] = (long long)off; off += cb_skip; }
+  }
+  n.sf_fp[n.NL - 1] = (long long)off; off += cb_last;
+  f_cursor += off;
+  off = 0;
+  n.sb_fp[n.NL - 1] = (long long)off; off += cb_blast;
+  for (int l = n.NL - 2; l >= 1; --l) { n.sb_hid[l] = (long long)off; off += (size_t)8 * cb_hid; }
+  if (n.dx0) { n.sb_fp[0] = (long long)off; off += (size_t)2 * cb_bl0h; }
+  b_cursor += off;
+  return cb_hid == 49152 && cb_blast == 2 * AF_HID * 16 && 2 * cb_bl0h == 32 * 2 * 64 * 16;
+}
+
 // The kernels walk the weight stream with compile-time chunk sizes (mlp.hip ChunkBytes): the planned layout must
 // be exactly that sequence, contiguous.
 bool check_chunk_plan(const NetDesc& n) {
@@ -226,6 +262,15 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
     a.bias_img_off = (uint32_t)(n.bias_base + (size_t)l * AF_HID);
     a.pe_kind = n.pe_kind;
     a.hid_cols = l == 0 ? (n.in_kind == AF_IN_XYT ? n.in_feat[l] : 0) : AF_HID;
+    // bf16x6 chain streams: which block of the net's forward / backward stream this job's weights go to
+    const bool last_l = l == n.NL - 1;
+    a.sf_k0 = 0; a.sf_mpad = last_l ? 4 : AF_HID; a.sb_mpad = l == 0 ? 64 : AF_HID;
+    if (l == 0 || last_l)  { a.sf_kind = 0; a.sf_off = (int32_t)(n.sf_base + n.sf_fp[l]); }
+    else if (col0 == 0)    { a.sf_kind = 1; a.sf_off = (int32_t)(n.sf_base + n.sf_hid[l]); }
+    else                   { a.sf_kind = 0; a.sf_off = (int32_t)(n.sf_base + n.sf_fp[l]); a.sf_k0 = AF_HID; }
+    if (n.b_off_img[l] < 0)      { a.sb_kind = 0; a.sb_off = -1; }
+    else if (last_l || l == 0)   { a.sb_kind = 0; a.sb_off = (int32_t)(n.sb_base + n.sb_fp[l]); }
+    else                         { a.sb_kind = 1; a.sb_off = (int32_t)(n.sb_base + n.sb_hid[l]); }
     sc.ajobs.push_back(a);
   };
   for (const NetUse& u : uses) {
@@ -339,18 +384,20 @@ void free_net(NetDesc& n) {
   (void)hipFree(n.coords); (void)hipFree(n.x0_tile);
 }
 
-FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train) {
+// bf: the launch goes to the bf16x6 chains (mlpbf.hip), which walk the net's bf16 stream; the fp32 chains (mlp.hip, and always
+// the 16-row pre-train chains of mlp16.hip) walk the fp32 images
+FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train, bool bf) {
   FwdArgs a{};
-  a.wimg = h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
+  a.wimg = bf ? (const float*)(h->img_sf + n.sf_base) : h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
   a.in = in; a.in1 = nullptr; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
   a.NT = NT; a.nt_stride = NT;
   return a;
 }
 
-BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT) {
+BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT, bool bf) {
   BwdArgs a{};
-  a.wimg = h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
+  a.wimg = bf ? (const float*)(h->img_sb + n.sb_base) : h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
   a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
   a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT;
   return a;
@@ -387,7 +434,8 @@ AdamHyper adam_hyper(double lr, long long step) {
 int repack(af_handle* h, Sched& sc) {
   AdamArgs a{};
   a.jobs = sc.d_ajobs; a.partial = h->partial;
-  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img};
+  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb};
+  a.nan_flag = h->nan_flag;
   LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 0, h->stream));
   return 0;
 }
@@ -410,7 +458,8 @@ int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool
   }
   if (m.n == 0) return 0;
   Timer t(h, cls, fl);
-  LCHK(af_launch_fwd_multi(&m, train ? 1 : 0, h->stream));
+  if (h->mlp_mode) LCHK(af_launch_fwd_multi_bf(&m, train ? 1 : 0, h->stream));
+  else             LCHK(af_launch_fwd_multi(&m, train ? 1 : 0, h->stream));
   return 0;
 }
 int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
@@ -422,7 +471,8 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   }
   if (m.n == 0) return 0;
   Timer t(h, cls, fl);
-  LCHK(af_launch_bwd_multi(&m, h->stream));
+  if (h->mlp_mode) LCHK(af_launch_bwd_multi_bf(&m, h->stream));
+  else             LCHK(af_launch_bwd_multi(&m, h->stream));
   return 0;
 }
 FwdArgs tile_range(FwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
@@ -442,18 +492,27 @@ void plan_mapping_split(int ncu, int NT_map, int NT_atlas, int dep_rows, int& T1
 }
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
-int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops) {
+int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops, bool check_counts = true) {
   { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock}; LCHK(af_launch_dw(&d, sc.nwg, h->dw_mode, h->stream)); }
   {
     Timer t(h, T_ADAM);
     AdamArgs a{};
     a.jobs = sc.d_ajobs; a.partial = h->partial;
-    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img};
+    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb};
     a.hy = adam_hyper(h->cfg.lr, step);
     a.grad_out = h->debug ? h->grads : nullptr;
-    a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = loss_nblk;
+    a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = loss_nblk; a.nan_flag = h->nan_flag;
+    a.check_counts = check_counts ? 1 : 0;
     LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 1, h->stream));
   }
+  return 0;
+}
+
+// Fetch and clear the device-side NaN flag (the stream is idle).  Non-zero: the reference would be carrying NaNs from here on.
+int take_nan_flag(af_handle* h, int& flag) {
+  flag = 0;
+  HCHK(hipMemcpy(&flag, h->nan_flag, 4, hipMemcpyDeviceToHost));
+  if (flag) HCHK(hipMemset(h->nan_flag, 0, 4));
   return 0;
 }
 
@@ -494,10 +553,10 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
   // atlas workgroups leave idle.  The backward pass mirrors it (the remainder needs no atlas gradient).
   int rc, T1, T2;
   plan_mapping_split(h->ncu, NT_map, NT_atlas, 3 * N, T1, T2);
-  const FwdArgs fm = fwd_args(h, M, M.coords, M.out_buf, NT_map, true);
+  const FwdArgs fm = fwd_args(h, M, M.coords, M.out_buf, NT_map, true, h->mlp_mode != 0);
   if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, tile_range(fm, 0, T1), nseg * N}}, true)) != 0) return rc;
   if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_MAP1, tile_range(fm, T1, T2), nseg * N},
-                                    {AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true), 3 * N},
+                                    {AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true, h->mlp_mode != 0), 3 * N},
                                     {AF_NET_MAP1, tile_range(fm, T2, NT_map), nseg * N}}, true)) != 0) return rc;
   {
     Timer t(h, T_LOSS);
@@ -511,8 +570,8 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
   }
   h->adam_step += 1;
   {
-    BwdArgs ba = bwd_args(h, A, NT_atlas); ba.din0 = M.dout; ba.nrows = 3 * N;
-    const BwdArgs bm = bwd_args(h, M, NT_map);
+    BwdArgs ba = bwd_args(h, A, NT_atlas, h->mlp_mode != 0); ba.din0 = M.dout; ba.nrows = 3 * N;
+    const BwdArgs bm = bwd_args(h, M, NT_map, h->mlp_mode != 0);
     if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_MAP1, tile_range(bm, T1, T2), nseg * N}, {AF_NET_ATLAS, ba, 3 * N},
                                       {AF_NET_MAP1, tile_range(bm, T2, NT_map), nseg * N}})) != 0) return rc;
     if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_MAP1, tile_range(bm, 0, T1), nseg * N}})) != 0) return rc;
@@ -552,12 +611,12 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
   int rc;
   const int wg_atlas = (NT_atlas + 3) / 4, pad = (h->ncu - wg_atlas % h->ncu) % h->ncu;
   const int T_al = std::max(0, NT_alpha - 4 * pad);                 // alpha tiles [T_al, NT_alpha) ride with the atlas
-  const FwdArgs fal = fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true);
-  FwdArgs fat = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true);
+  const FwdArgs fal = fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true, h->mlp_mode != 0);
+  FwdArgs fat = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true, h->mlp_mode != 0);
   fat.in1 = M2.out_buf; fat.split_row = 3 * N;
   if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_ALPHA, tile_range(fal, 0, T_al), 5 * N},
-                                    {AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true), nseg * N},
-                                    {AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true), nseg * N}}, true)) != 0) return rc;
+                                    {AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true, h->mlp_mode != 0), nseg * N},
+                                    {AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true, h->mlp_mode != 0), nseg * N}}, true)) != 0) return rc;
   if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fat, 6 * N}, {AF_NET_ALPHA, tile_range(fal, T_al, NT_alpha), 5 * N}}, true)) != 0) return rc;
   {
     Timer t(h, T_LOSS);
@@ -576,12 +635,12 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
   }
   h->adam_step += 1;
   {   // the mapping chains need the atlas chain's input gradient (rows < 3N): atlas (+ alpha top-up) first
-    BwdArgs ba = bwd_args(h, A, NT_atlas);
+    BwdArgs ba = bwd_args(h, A, NT_atlas, h->mlp_mode != 0);
     ba.din0 = M1.dout; ba.din1 = M2.dout; ba.split_row = 3 * N; ba.nrows = 6 * N;
-    const BwdArgs bal = bwd_args(h, AL, NT_alpha);
+    const BwdArgs bal = bwd_args(h, AL, NT_alpha, h->mlp_mode != 0);
     if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_ATLAS, ba, 6 * N}, {AF_NET_ALPHA, tile_range(bal, T_al, NT_alpha), 5 * N}})) != 0) return rc;
-    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, bwd_args(h, M1, NT_map), nseg * N},
-                                      {AF_NET_MAP2, bwd_args(h, M2, NT_map), nseg * N}})) != 0) return rc;
+    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, bwd_args(h, M1, NT_map, h->mlp_mode != 0), nseg * N},
+                                      {AF_NET_MAP2, bwd_args(h, M2, NT_map, h->mlp_mode != 0), nseg * N}})) != 0) return rc;
   }
   const double dwf = (double)nseg * N * (kFlopFwd[AF_NET_MAP1] + kFlopFwd[AF_NET_MAP2]) + 6.0 * N * kFlopFwd[AF_NET_ATLAS] + 5.0 * N * kFlopFwd[AF_NET_ALPHA];
   return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
@@ -668,6 +727,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   af_handle* h = new af_handle();
   h->cfg = *cfg; h->device = device_ordinal; h->seg = seg;
   if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : 1;
+  if (const char* e_ = getenv("AF_MLP_FP32")) h->mlp_mode = atoi(e_) ? 0 : 1;
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
   auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
@@ -675,7 +735,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
   h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init());
+  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init()); CCHK((hipError_t)af_mlp_bf_init());
 
   describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
   describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
@@ -687,7 +747,12 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   for (NetDesc& n : h->nets) if (n.used) {
     n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc);
     if (!check_chunk_plan(n)) { h->fail(AF_EINVAL, "weight-image plan does not match the kernels' chunk sequence"); return die(AF_EINVAL); }
+    if (!plan_streams_bf(n, h->sf_bytes, h->sb_bytes)) { h->fail(AF_EINVAL, "bf16 stream plan does not match the kernels' chunk sizes"); return die(AF_EINVAL); }
   }
+  h->sf_bytes += 49152 + 65536; h->sb_bytes += 49152 + 65536;   // every LDS stage copies a full slot: keep the over-read in bounds
+  if (h->sf_bytes >= ((size_t)1 << 31) || h->sb_bytes >= ((size_t)1 << 31)) { h->fail(AF_EINVAL, "stream images exceed 2 GB"); return die(AF_EINVAL); }
+  CCHK(hipMalloc((void**)&h->img_sf, h->sf_bytes)); CCHK(hipMalloc((void**)&h->img_sb, h->sb_bytes));
+  CCHK(hipMemset(h->img_sf, 0, h->sf_bytes)); CCHK(hipMemset(h->img_sb, 0, h->sb_bytes));
   fc += AF_CHUNK_MAX / 4; bc += AF_CHUNK_MAX / 4;   // every LDS stage copies a full 64 KB buffer: keep the over-read in bounds
   h->total_params = pc; h->img_f_floats = fc; h->img_b_floats = bc; h->bias_floats = biasc;
   CCHK(dalloc(&h->params, pc)); CCHK(dalloc(&h->adam_m, pc)); CCHK(dalloc(&h->adam_v, pc));
@@ -710,6 +775,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   h->loss_nblk_cap = (std::max(N, rows_pre) + 255) / 256;
   CCHK(dalloc(&h->loss_part, (size_t)h->loss_nblk_cap * AF_LOSS_W)); CCHK(hipMemset(h->loss_part, 0, (size_t)h->loss_nblk_cap * AF_LOSS_W * 4));
   CCHK(dalloc(&h->counts, 2)); CCHK(hipMemset(h->counts, 0, 8));
+  CCHK(dalloc(&h->nan_flag, 1)); CCHK(hipMemset(h->nan_flag, 0, 4));
   // schedules
   bool ok = true;
   for (int v = 0; v < 2 && ok; ++v) {
@@ -741,8 +807,8 @@ void af_destroy(af_handle* h) {
   for (NetDesc& n : h->nets) if (n.used) free_net(n);
   for (Sched& s : h->sched) { (void)hipFree(s.d_jobs); (void)hipFree(s.d_ajobs); (void)hipFree(s.d_segs); }
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
-  (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table);
-  (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts);
+  (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table); (void)hipFree(h->img_sf); (void)hipFree(h->img_sb);
+  (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts); (void)hipFree(h->nan_flag);
   (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
   (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -843,6 +909,7 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
 }
 
 int af_set_dw_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->dw_mode = mode; return AF_OK; }
+int af_set_mlp_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->mlp_mode = mode; return AF_OK; }
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
 int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
 int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset) {
@@ -900,19 +967,20 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
       // 16-row chains (mlp16.hip): the batch is smaller than one round of the chip, so a step is bound by the latency
       // of one tile chain — half the rows per wave, half the latency
-      { Timer t(h, T_FWD_1, (double)NB * kFlopFwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true);
+      { Timer t(h, T_FWD_1, (double)NB * kFlopFwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
         if (af_launch_fwd16(net, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      { Timer t(h, T_BWD_2, (double)NB * kFlopDx[net]); const BwdArgs ba = bwd_args(h, M, NT);
+      { Timer t(h, T_BWD_2, (double)NB * kFlopDx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
         if (af_launch_bwd16(net, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
-      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * kFlopFwd[net]);
+      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * kFlopFwd[net], false);
     }
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
   if (d_ys) { (void)hipFree(d_ys); (void)hipFree(d_xs); }
   if (rc) return rc;
   if (e != hipSuccess) return h->fail(AF_EHIP, "af_pretrain sync", e);
+  { int dev_nan = 0; int r2 = take_nan_flag(h, dev_nan); if (r2) return r2; if (dev_nan) return h->fail(AF_ENAN, "af_pretrain: NaN loss or non-finite parameter"); }
   if (losses_out) {
     std::vector<float> tmp(steps * AF_LOSS_W);
     HCHK(hipMemcpy(tmp.data(), h->loss_log, steps * AF_LOSS_W * 4, hipMemcpyDeviceToHost));
@@ -948,6 +1016,8 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
   if (rc) return rc;
   if (e != hipSuccess) return h->fail(AF_EHIP, "af_train_steps sync", e);
   std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
+  int dev_nan = 0;
+  if ((rc = take_nan_flag(h, dev_nan)) != 0) return rc;
   if (losses_out) {
     std::vector<float> tmp((size_t)n_iters * AF_LOSS_W);
     HCHK(hipMemcpy(tmp.data(), h->loss_log, (size_t)n_iters * AF_LOSS_W * 4, hipMemcpyDeviceToHost));
@@ -986,6 +1056,8 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
     }
     if (nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss (a batch without valid flow pixels, as in the reference, or divergence)");
   }
+  // also without a loss buffer: a non-finite parameter, a NaN loss term or an empty flow-match set seen by k_adam
+  if (dev_nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss or non-finite parameter (a batch without valid flow pixels, as in the reference, or divergence)");
   return AF_OK;
 }
 
@@ -1048,7 +1120,7 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
   const int NT = tiles_of(rows);
   HCHK(hipMemsetAsync(h->r_coords, 0, (size_t)NT * 32 * 16, h->stream));
   HCHK(hipMemcpyAsync(h->r_coords, in, (size_t)rows * 16, hipMemcpyHostToDevice, h->stream));
-  FwdArgs fa = fwd_args(h, h->nets[net], h->r_coords, h->r_uv, NT, false);
+  FwdArgs fa = fwd_args(h, h->nets[net], h->r_coords, h->r_uv, NT, false, h->mlp_mode != 0);
   if (h->nets[net].in_kind != AF_IN_XYT) { fa.in_scale = 1.f; fa.in_shift0 = 0.f; fa.in_shift1 = 0.f; }
   { int rc2 = launch_fwd(h, T_FWD_1, {{net, fa, rows}}, false); if (rc2) return rc2; }
   HCHK(hipMemcpyAsync(out, h->r_uv, (size_t)rows * 16, hipMemcpyDeviceToHost, h->stream));
@@ -1067,17 +1139,17 @@ int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out) {
   const float half_main = (float)(std::max(h->cfg.resx, h->cfg.resy) / 2.0);
   const float t = (float)((double)frame / (F / 2.0) - 1.0);     // evaluate.py:656 computes t in Python floats
   LCHK(af_launch_frame_coords(h->r_coords, h->cfg.resx, h->cfg.resy, half_main, t, NT * 32, h->stream));
-  FwdArgs fm = fwd_args(h, h->nets[AF_NET_MAP1], h->r_coords, h->r_uv, NT, false);
+  FwdArgs fm = fwd_args(h, h->nets[AF_NET_MAP1], h->r_coords, h->r_uv, NT, false, h->mlp_mode != 0);
   if (!h->seg) {
     if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, fm, npix}}, false)) != 0) return rc;
-    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false);
+    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, NT, false, h->mlp_mode != 0);
     if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fa, npix}}, false)) != 0) return rc;
     LCHK(af_launch_frame_finish(h->r_t, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));
   } else {   // evaluate.py:302-337
-    FwdArgs f2 = fwd_args(h, h->nets[AF_NET_MAP2], h->r_coords, h->r_uv2, NT, false);
-    FwdArgs fl = fwd_args(h, h->nets[AF_NET_ALPHA], h->r_coords, h->r_al, NT, false);
+    FwdArgs f2 = fwd_args(h, h->nets[AF_NET_MAP2], h->r_coords, h->r_uv2, NT, false, h->mlp_mode != 0);
+    FwdArgs fl = fwd_args(h, h->nets[AF_NET_ALPHA], h->r_coords, h->r_al, NT, false, h->mlp_mode != 0);
     if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_ALPHA, fl, npix}, {AF_NET_MAP1, fm, npix}, {AF_NET_MAP2, f2, npix}}, false)) != 0) return rc;
-    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, 2 * NT, false);
+    FwdArgs fa = fwd_args(h, h->nets[AF_NET_ATLAS], h->r_uv, h->r_t, 2 * NT, false, h->mlp_mode != 0);
     fa.in1 = h->r_uv2; fa.split_row = NT * 32;
     if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fa, 2 * NT * 32}}, false)) != 0) return rc;
     LCHK(af_launch_frame_finish_seg(h->r_t, h->r_al, (size_t)NT * 32, h->table, h->r_rgb, h->r_sse, npix, (size_t)frame * npix, h->stream));

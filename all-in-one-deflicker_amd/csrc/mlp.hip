@@ -15,113 +15,6 @@
 // list of independent (net, row-tile range) parts.
 #include "mlp_common.h"
 
-#ifndef AF_SGB
-#define AF_SGB 1     // explicit MFMA / memory-instruction interleave (sched_group_barrier) inside every k-group
-#endif
-#ifndef AF_AFRAG
-#define AF_AFRAG 1   // A fragments in AGPRs (see lds_frag)
-#endif
-
-// One A fragment (four consecutive k of one output row) from the LDS weight image, pinned to the accumulator half of
-// the register file: ds_read_b128 writes AGPRs directly and the MFMA takes its A operand from there, so the 64
-// fragment registers do not compete with the 128 activation registers for the 256 architectural VGPRs (with all of
-// them in VGPRs the allocator is full and sinks every group's reads to the end of the previous group, where their
-// latency is exposed behind an s_waitcnt lgkmcnt(0)).
-AF_DEV f32x4 lds_frag(const char* p) { return *(const f32x4*)p; }
-// The pin sits at the fragment's first USE (top of its k-group), not at the load: the compiler's s_waitcnt for the
-// read lands there too, a whole group (32 MFMAs) after the read was issued.
-AF_DEV void pin_acc(f32x4& v) {
-#if AF_AFRAG
-  asm("" : "+a"(v));
-#endif
-}
-
-// acc[T] += A(image in LDS) * b[B0 + 4*g + p]  for NG k-groups; a_lds already includes the lane offset
-// (h*MPAD + j)*16.  NP < 4 skips reduction indices that are structurally zero.  hook(g) is called once per
-// k-group right after that group's A-fragment reads were issued: work placed there (LDS-DMA issue of the
-// next weight chunk, stores of the previous layer's activations) runs in the shadow of the group's MFMAs
-// instead of in front of an empty matrix pipe.
-template <int MT, int NG, int B0, int NP, bool ZI, int NB, class Hook, int... Gs>
-AF_DEV void mm_block_impl(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook& hook, std::integer_sequence<int, Gs...>) {
-  constexpr int MPAD = MT * 32;
-  f32x4 a[2][MT];
-#pragma unroll
-  for (int T = 0; T < MT; ++T) a[0][T] = lds_frag(a_lds + T * 32 * 16);
-  if constexpr (AF_ABL & 8) {
-#pragma unroll
-    for (int T = 0; T < MT; ++T) a[1][T] = a[0][T];
-  }
-  auto step = [&](auto gi) {
-    constexpr int g = decltype(gi)::value;
-#pragma unroll
-    for (int T = 0; T < MT; ++T) pin_acc(a[g & 1][T]);
-    if constexpr (g + 1 < NG && !(AF_ABL & 8)) {
-#pragma unroll
-      for (int T = 0; T < MT; ++T) a[(g + 1) & 1][T] = lds_frag(a_lds + ((g + 1) * 2 * MPAD + 32 * T) * 16);
-    }
-    hook(gi);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-#pragma unroll
-      for (int T = 0; T < MT; ++T) {
-        if constexpr (ZI && g == 0) {
-          if (p == 0) { const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][T][0], b[B0], z, 0, 0, 0); continue; }
-        }
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][T][p], b[B0 + g * 4 + p], acc[T], 0, 0, 0);
-      }
-    }
-#if AF_SGB
-    // Issue order inside the group: one LDS fragment read and one VMEM instruction (LDS-DMA piece / tile store) behind
-    // each MFMA, so that every memory instruction issues in the shadow of a 64-cycle MFMA instead of in one burst
-    // behind which the matrix pipe drains (hipcc's own order: 24 MFMAs, then 8 reads + 2 DMA + up to 16 stores).
-#pragma unroll
-    for (int i = 0; i < NP * MT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    }
-#endif
-    if constexpr (!(AF_ABL & 16)) __builtin_amdgcn_sched_barrier(0);     // keep each group's DMA / stores inside its own MFMA shadow
-  };
-  (step(GIdx<Gs>{}), ...);
-}
-// ZI: the accumulators start at zero — the first MFMA of each takes an inline-constant 0 as C instead of
-// a previously zeroed register block (saves MT*16 v_accvgpr_write per layer in the backward chain).
-template <int MT, int NG, int B0, int NP, bool ZI = false, int NB, class Hook>
-AF_DEV void mm_block(f32x16 (&acc)[MT], const float (&b)[NB], const char* a_lds, Hook&& hook) {
-  mm_block_impl<MT, NG, B0, NP, ZI>(acc, b, a_lds, hook, std::make_integer_sequence<int, NG>{});
-}
-
-AF_DEV void init_bias(f32x16 (&acc)[8], const char* smem, int layer, int h) {
-  const char* b = smem + AF_BIAS_LDS + (layer * AF_HID + 4 * h) * 4;
-#pragma unroll
-  for (int T = 0; T < 8; ++T) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = *(const f32x4*)(b + (32 * T + 8 * q) * 4);
-      acc[T][q * 4 + 0] = b4[0]; acc[T][q * 4 + 1] = b4[1]; acc[T][q * 4 + 2] = b4[2]; acc[T][q * 4 + 3] = b4[3];
-    }
-  }
-}
-
-// Store 1/8 (feature tile T) of a C-layout block (reg = 16T+4q+p <-> feature 32T+8q+4h+p) into a T-layout
-// tile [256][32].
-template <int T>
-AF_DEV void store_tile_part(const float (&v)[128], __amdgpu_buffer_rsrc_t r, int voff) {
-  // the 128-B steps between p = 0..3 ride in the instruction's immediate offset: one soffset per (T, q)
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) af_bs32(v[T * 16 + rr], r, voff + (rr & 3) * 128, (32 * T + 8 * (rr >> 2)) * 128);
-}
-
-// Deferred stores of one 32x256 block: one feature tile per k-group of the following GEMM block.
-// A dead wave (tile past the end) carries a zero-length buffer descriptor: its stores are dropped by the
-// hardware bounds check, so the store sites need no branch.
-struct TileStore {
-  __amdgpu_buffer_rsrc_t r; int voff;
-  template <int G> AF_DEV void part(const float (&v)[128]) { if constexpr (G < 8 && !(AF_ABL & 1)) store_tile_part<G>(v, r, voff); }
-};
-
 template <class NS, bool TRAIN>
 AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
@@ -136,7 +29,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
 
-  stage_bias<NS::NL>(a.bias, smem, tid);
+  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS, tid);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
   float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
   {
@@ -219,14 +112,14 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   // ---- layer 0
   {
     const char* buf = cs.next<CB::L0>();            // its barrier also publishes the bias rows
-    init_bias(acc, smem, 0, h);
+    init_bias(acc, smem + AF_BIAS_LDS, 0, h);
     mm_block<8, NS::K0G, 0, 4>(acc, pe, buf + a_off8, hook_dma);
   }
   relu_out(0);
 
   // ---- hidden layers 1 .. NL-2
   for (int l = 1; l <= NS::NL - 2; ++l) {
-    init_bias(acc, smem, l, h);
+    init_bias(acc, smem + AF_BIAS_LDS, l, h);
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
 
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
-  stage_bias<NS::NL>(a.bias, smem, tid);
+  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS, tid);
 
   float x0[4];
   {

@@ -1,0 +1,490 @@
+// mlpbf.hip — the register-chained fused coordinate-MLP kernels of mlp.hip with their 256x256 hidden-layer products on
+// the bf16 matrix pipe, fp32-faithful ("bf16x6", bfsplit.h): weights arrive pre-split into three bf16 images (hi, mid,
+// lo — emitted by k_adam next to the fp32 views), activations are split in registers one k-step (16 features) at a
+// time, and every product block accumulates the six leading partial products in the fp32 accumulators.  K = 16 retires in
+// 6 x 32 cycles instead of the 8 x 64 of v_mfma_f32_32x32x2_f32: 2.7x the rate of the fp32 matrix pipe with fp32-level
+// round-off (tests/test_split_precision.py).  Same tiles, same C-layout chaining, same launch structure as mlp.hip
+// (src/models/stage_1/implicit_neural_networks.py:62-80 forward; the dX half of loss.backward(), stage1_neural_atlas.py:230).
+//
+// What stays on the fp32 pipe: the narrow blocks — layer 0 (K = 3 / 30 / 40), the positional-encoding columns of the skip
+// layers, the 1..3-row output layer and, backward, the output layer and the atlas net's layer-0 (dPE) block.
+//
+// Weight stream: one contiguous image per net in consumption order; fp32 blocks as in mlp.hip, a hidden layer as eight
+// 48 KB chunks of two k-steps: chunk-local index ((s*8 + T)*3 + level)*1024 + (h*32 + m)*16 holds the eight bf16
+// W[32T + m][k(h, 0..7)] of k-step s, with k(h, i) = 32(s>>1) + 8(2(s&1) + i/4) + 4h + i%4 — exactly the eight features
+// lane half h holds in registers 8s .. 8s+7 of the C-layout (one ds_read_b128 per tile, level and k-step).
+// Two LDS slots of 48 KB; the barrier that publishes chunk c+1 sits 24 MFMAs before the end of chunk c (every wave then
+// holds the rest of chunk c in registers), so the next chunk's first fragments and the DMA of chunk c+2 start in the
+// shadow of chunk c's last product group.
+#include "mlp_common.h"
+#include "bfsplit.h"
+
+#define AF_SLOT_BF 49152
+#define AF_BIAS_LDS_BF (2 * AF_SLOT_BF)
+#define AF_LDS_BYTES_BF (2 * AF_SLOT_BF + AF_MAX_LAYERS * AF_HID * 4)
+
+template <class NS> struct ChunkBytesBf {
+  static constexpr int L0 = ChunkBytes<NS>::L0;
+  static constexpr int HID = AF_SLOT_BF;                 // x8 per hidden layer
+  static constexpr int SKIP = ChunkBytes<NS>::SKIP;
+  static constexpr int LAST = ChunkBytes<NS>::LAST;
+  static constexpr int BLAST = ChunkBytes<NS>::BLAST;
+  static constexpr int BL0H = 16 * 2 * 64 * 16;          // half of the backward layer-0 block (Mpad 64): two chunks of 32 KB
+};
+static_assert(ChunkBytesBf<NsAtlas>::L0 <= AF_SLOT_BF && ChunkBytesBf<NsAtlas>::SKIP <= AF_SLOT_BF && ChunkBytesBf<NsAlpha>::L0 <= AF_SLOT_BF, "fp32 blocks must fit a slot");
+
+// Weight-chunk stream over two LDS slots.  Every stage copies a full slot (12 x 1 KB per wave) whatever the chunk's real
+// size (the images are padded for the over-read); issue sites are branch-free (a site beyond the twelfth re-copies the
+// last piece).  publish<B>() makes the chunk being staged (B bytes long) visible and starts staging the one behind it into
+// the slot the previous chunk occupied — callers place it where every wave has issued its last read of that chunk.
+struct BfStream {
+  static constexpr int NI = AF_SLOT_BF / 4096;
+  const char* src; char* smem; int wave, stg; char* p_dst; int p_it;
+  AF_DEV void begin_stage() { p_dst = smem + (stg & 1) * AF_SLOT_BF + wave * 1024; p_it = 0; }
+  AF_DEV void issue1() {
+    const int k = p_it < NI ? p_it : NI - 1;
+    af_glds16(src + k * 4096, p_dst + k * 4096);
+    ++p_it;
+  }
+  AF_DEV void start(const void* img, int tid, int wave_) { src = (const char*)img + tid * 16; wave = wave_; stg = 0; begin_stage(); }
+  AF_DEV const char* publish(int BYTES) {
+    while (p_it < NI) issue1();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* cur = smem + (stg & 1) * AF_SLOT_BF;
+    src += BYTES; ++stg;
+    begin_stage();
+    return cur;
+  }
+};
+
+struct BfPipe { f32x4 fl[8]; DwSplit b; };     // carried between k-steps: the lo-level fragments and the split B operand of the NEXT k-step
+
+AF_DEV f32x4 bf_frag(const char* lane_base, int sl, int T, int lvl) { return *(const f32x4*)(lane_base + ((sl * 8 + T) * 3 + lvl) * 1024); }
+AF_DEV f32x16 bf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+AF_DEV DwSplit bf_split_in(const float (&in)[128], int s) {
+  const f32x4 lo = {in[8 * s], in[8 * s + 1], in[8 * s + 2], in[8 * s + 3]}, hi = {in[8 * s + 4], in[8 * s + 5], in[8 * s + 6], in[8 * s + 7]};
+  return dw_split8(lo, hi);
+}
+template <int N> AF_DEV void bf_sgb() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA, then at most one LDS read, two VALU, one VMEM behind it
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One k-step (16 input features) of a 256 -> 256 product.  S: k-step of the layer (0..15), its chunk-local index is S & 1.
+// ZI: the accumulators start at zero (backward chain): the very first MFMA of each takes a literal 0 as C.
+// An odd k-step publishes the chunk behind its own before its last product group (after_bytes: the size of the chunk
+// behind the whole block, used by k-step 15) and fetches the lo-level fragments of that chunk's first k-step — inside a
+// block only: across layers nothing is carried (bf_enter), so that every layer of the runtime loop runs the same code.
+template <int S, bool ZI, class Hook>
+AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& store_hook) {
+  constexpr bool NEXT_BF = S != 15;
+  constexpr int sl = S & 1;
+  constexpr bool last_in_chunk = sl == 1;
+  f32x4 fm[8], fh[8];
+  // ---- group 1: W_lo x B_hi (8 MFMAs); fetch W_mid
+#pragma unroll
+  for (int T = 0; T < 8; ++T) { pin_acc(pp.fl[T]); fm[T] = bf_frag(lane_base, sl, T, 1); }
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    if constexpr (ZI && S == 0) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[T] = bf_mfma(pp.fl[T], pp.b.h, z);
+    } else {
+      acc[T] = bf_mfma(pp.fl[T], pp.b.h, acc[T]);
+    }
+  }
+  cs.issue1();
+  bf_sgb<8>();
+  // ---- group 2: W_mid x (B_mid, B_hi) (16 MFMAs); fetch W_hi; the deferred tile stores of this k-step's feature tile
+#pragma unroll
+  for (int T = 0; T < 8; ++T) { pin_acc(fm[T]); fh[T] = bf_frag(lane_base, sl, T, 0); }
+#pragma unroll
+  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fm[T], pp.b.m, acc[T]);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fm[T], pp.b.h, acc[T]);
+  cs.issue1(); cs.issue1();
+  store_hook(GIdx<S>{});
+  bf_sgb<16>();
+  // ---- publish the next chunk (odd k-steps): every read of this chunk has been issued; the slot can be refilled
+  const char* nxt_lane = lane_base;
+  if constexpr (last_in_chunk) nxt_lane = cs.publish(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
+  // ---- group 3: W_hi x (B_lo, B_mid, B_hi) (24 MFMAs); fetch the next k-step's W_lo and split its B operand
+  DwSplit bn = pp.b;
+  f32x4 fln[8];
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    pin_acc(fh[T]);
+    if constexpr (!last_in_chunk) fln[T] = bf_frag(lane_base, 1, T, 2);
+    else if constexpr (NEXT_BF)   fln[T] = bf_frag(nxt_lane, 0, T, 2);
+    else                          fln[T] = pp.fl[T];
+  }
+  if constexpr (S + 1 < 16) bn = bf_split_in(in, S + 1);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.l, acc[T]);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.m, acc[T]);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.h, acc[T]);
+  cs.issue1(); cs.issue1(); cs.issue1();
+  bf_sgb<24>();
+#pragma unroll
+  for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
+  pp.b = bn;
+  lane_base = nxt_lane;
+}
+
+// A whole 256 -> 256 product (16 k-steps = 8 chunks).  On entry the first chunk is published at lane_base (bf_enter has
+// fetched its first fragments); on exit lane_base addresses the published chunk behind the block (after_bytes long).
+template <bool ZI, class Hook, int... Ss>
+AF_DEV void bf_block_impl(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook& hook, std::integer_sequence<int, Ss...>) {
+  (bf_kstep<Ss, ZI>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook), ...);
+}
+template <bool ZI, class Hook>
+AF_DEV void bf_block(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& hook) {
+  bf_block_impl<ZI>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook, std::make_integer_sequence<int, 16>{});
+}
+// entering a block: the lo-level fragments and the split B operand of its first k-step
+AF_DEV void bf_enter(BfPipe& pp, const float (&in)[128], const char* lane_base) {
+#pragma unroll
+  for (int T = 0; T < 8; ++T) pp.fl[T] = bf_frag(lane_base, 0, T, 2);
+  pp.b = bf_split_in(in, 0);
+}
+
+template <class NS, bool TRAIN>
+AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+  int tile = a.tile0 + wg * 4 + wave;
+  const bool live = tile < a.NT;
+  if (!live) tile = a.NT - 1;
+  const int row = tile * 32 + j;
+
+  using CB = ChunkBytesBf<NS>;
+  BfStream cs; cs.smem = smem;
+  cs.start(a.wimg, tid, wave);
+  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS_BF, tid);
+  constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
+  float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
+  {
+    const f32x4 v = row < a.split_row ? *(const f32x4*)(a.in + (size_t)row * 4) : *(const f32x4*)(a.in1 + (size_t)(row - a.split_row) * 4);
+    if constexpr (NS::IN == AF_IN_XYT) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) pe[p] = (h == 0 && p < 3) ? v[p] : 0.f;
+    } else if constexpr (NS::IN == AF_IN_PE2) {
+      const float sh = row < a.split_row ? a.in_shift0 : a.in_shift1;
+      const float x0 = v[0] * a.in_scale + sh, x1 = v[1] * a.in_scale + sh;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const float b = h ? __builtin_ldexpf(3.14159265358979323846f, 2 * g + 1) : __builtin_ldexpf(3.14159265358979323846f, 2 * g);
+        const float p0 = x0 * b, p1 = x1 * b;
+        pe[g * 4 + 0] = sinf(p0); pe[g * 4 + 1] = sinf(p1); pe[g * 4 + 2] = cosf(p0); pe[g * 4 + 3] = cosf(p1);
+      }
+    } else {   // AF_IN_PE3: lane half h owns k in {2h, 2h+1} (+ sin/cos triple of k = 4)
+      const float x[3] = {v[0], v[1], v[2]};
+      const float bA = __builtin_ldexpf(3.14159265358979323846f, 2 * h), bB = __builtin_ldexpf(3.14159265358979323846f, 2 * h + 1);
+      const float b4 = __builtin_ldexpf(3.14159265358979323846f, 4);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        pe[d] = sinf(x[d] * bA); pe[3 + d] = cosf(x[d] * bA);
+        pe[6 + d] = sinf(x[d] * bB); pe[9 + d] = cosf(x[d] * bB);
+        pe[12 + d] = h ? cosf(x[d] * b4) : sinf(x[d] * b4);
+      }
+      pe[15] = 0.f;
+    }
+    if constexpr (TRAIN && NS::PEG > 0) {
+      if (live) {   // PE features in reference feature order, T-layout [64][32], for the dW GEMMs
+        const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+        if constexpr (NS::IN == AF_IN_PE2) {
+#pragma unroll
+          for (int g = 0; g < 5; ++g)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) af_bs32(pe[g * 4 + p], r, (4 * h * 32 + j) * 4, (8 * g + p) * 128);
+        } else {
+#pragma unroll
+          for (int rho = 0; rho < 15; ++rho) {
+            if (rho < 12) af_bs32(pe[rho], r, (12 * h * 32 + j) * 4, rho * 128);
+            else          af_bs32(pe[rho], r, (3 * h * 32 + j) * 4, (24 + rho - 12) * 128);
+          }
+        }
+      }
+    }
+  }
+
+  const int a_off8 = (h * 256 + j) * 16;     // lane offset inside an fp32 Mpad = 256 image chunk
+  const int lane_off = (h * 32 + j) * 16;    // lane offset inside a bf16 chunk
+  const int voff_t = (4 * h * 32 + j) * 4;
+  const char* bias_lds = smem + AF_BIAS_LDS_BF;
+  f32x16 acc[8];
+  float in[128];
+  TileStore ts{af_rsrc(a.acts, 0), voff_t};
+  BfPipe pp;
+
+  auto relu_out = [&](int l) {               // acc -> in[] = relu(Z_l) = X_{l+1}; its stores are deferred
+    uint32_t mk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = af_relu(acc[T][r]);
+        in[T * 16 + r] = v;
+        if (TRAIN) mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __builtin_bit_cast(uint32_t, 0.f - v), 31);
+      }
+    if constexpr (TRAIN) {
+      if (live) {
+        u32x4 m4 = {mk[0], mk[1], mk[2], mk[3]};
+        *(u32x4*)(a.masks + (((size_t)l * a.nt_stride + tile) * 64 + lane) * 4) = m4;
+      }
+      ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    }
+  };
+  auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
+  auto hook_store = [&](auto gi) { if constexpr (TRAIN) ts.template part<decltype(gi)::value>(in); };
+
+  // ---- layer 0 (fp32 block); the chunk behind it is the first bf16 chunk of layer 1
+  const char* cur = cs.publish(CB::L0);             // its barrier also publishes the bias rows
+  init_bias(acc, bias_lds, 0, h);
+  mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
+  relu_out(0);
+  const char* lane_base = cs.publish(CB::HID) + lane_off;
+
+  // ---- hidden layers 1 .. NL-2: eight bf16 chunks each (+ the fp32 block of the skip columns); every iteration runs the
+  // same code — what lies behind a layer (its skip block, the next layer's first chunk, the output layer) is only a size
+#pragma unroll 1
+  for (int l = 1; l <= NS::NL - 2; ++l) {
+    init_bias(acc, bias_lds, l, h);
+    bf_enter(pp, in, lane_base);
+    const bool skip = NS::SKIP != 0 && ((NS::SKIP >> l) & 1);
+    const int behind = l == NS::NL - 2 ? CB::LAST : CB::HID;
+    bf_block<false>(acc, in, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, hook_store);
+    if constexpr (NS::SKIP != 0) {
+      if (skip) {
+        mm_block<8, NS::PEG, 0, 4>(acc, pe, lane_base - lane_off + a_off8, hook_dma);
+        lane_base = cs.publish(behind) + lane_off;
+      }
+    }
+    relu_out(l);
+  }
+  lane_base -= lane_off;
+
+  // ---- output layer (1..3 real outputs), tanh, on 4x4x1 fp32 MFMA blocks (see mlp.hip); lane_base = the chunk's LDS base
+  {
+    const char* buf = lane_base;
+    if constexpr (TRAIN) {     // the last hidden layer's activation tile
+      ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
+      ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
+    }
+    const char* al = buf + (h * 4 + (lane & 3)) * 16;
+    f32x4 o4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o4[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const f32x4 w = *(const f32x4*)(al + g * 2 * 4 * 16);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], in[4 * g + p], o4[p], 0, 0, 0);
+    }
+    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) {
+#pragma unroll
+      for (int g = 0; g < NS::PEG; ++g) {
+        const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+      }
+    }
+    const f32x4 bias = *(const f32x4*)(bias_lds + (NS::NL - 1) * AF_HID * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float z = (o4[0][i] + o4[1][i]) + (o4[2][i] + o4[3][i]);
+      z += __shfl_xor(z, 32);
+      o[i] = i < NS::OUT ? tanhf(z + bias[i]) : 0.f;
+    }
+    if (live && h == 0) *(f32x4*)(a.out + (size_t)row * 4) = o;
+  }
+}
+
+// x if bit (31 - e) of the sign-mask word is set, else 0 — as ONE opaque bit-field extract + and per element, tied to the
+// accumulator read: written with the C-level sbfe builtin hipcc turns the 128 tests into and / compare / select chains
+// and computes all 128 bit masks up front, 128 live registers that spill the chain.
+template <int E> AF_DEV float bf_mask_keep(float x, uint32_t mk) {
+  uint32_t r;
+  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %0, %3" : "=&v"(r) : "v"(mk), "n"(31 - ((E >> 4) & 1) * 16 - (E & 15)), "v"(x));
+  return __builtin_bit_cast(float, r);
+}
+template <int... Es> AF_DEV void bf_mask_all(float (&in)[128], const f32x16 (&acc)[8], const uint32_t (&mk)[4], std::integer_sequence<int, Es...>) {
+  ((in[Es] = bf_mask_keep<Es>(acc[Es >> 4][Es & 15], mk[Es >> 5])), ...);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward dX chain on the same scheme: dZ_{l-1} = (W_l^T dZ_l) . relu'(Z_{l-1}) with the bf16x3 image of W_l^T.
+template <class NS>
+AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+  int tile = a.tile0 + wg * 4 + wave;
+  const bool live = tile < a.NT;
+  if (!live) tile = a.NT - 1;
+  const int row = tile * 32 + j;
+
+  using CB = ChunkBytesBf<NS>;
+  BfStream cs; cs.smem = smem;
+  cs.start(a.wimg, tid, wave);
+
+  float dzl[4];
+  {
+    const f32x4 o = *(const f32x4*)(a.out + (size_t)row * 4);
+    const f32x4 d = *(const f32x4*)(a.dout + (size_t)row * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dzl[p] = (h == 0 && p < NS::OUT) ? d[p] * (1.f - o[p] * o[p]) : 0.f;
+    if (live && h == 0) {
+#pragma unroll
+      for (int p = 0; p < NS::OUT; ++p) a.dz_last[((size_t)tile * 32 + p) * 32 + j] = dzl[p];
+    }
+  }
+
+  const int a_off8 = (h * 256 + j) * 16;
+  const int lane_off = (h * 32 + j) * 16;
+  const int voff_t = (4 * h * 32 + j) * 4;
+  f32x16 acc[8];
+  float in[128];
+  TileStore ts{af_rsrc(a.dz, 0), voff_t};
+  BfPipe pp;
+
+  auto mask_out = [&](int l) {      // acc = dX_l; mask with sign bits of X_l (masks[l-1]) -> in[] = dZ_{l-1}
+    const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.nt_stride + tile) * 64 + lane) * 4);
+    const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
+    bf_mask_all(in, acc, mk, std::make_integer_sequence<int, 128>{});
+    ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+  };
+  auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
+  auto hook_store = [&](auto gi) { ts.template part<decltype(gi)::value>(in); };
+  auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
+
+  // ---- output layer (fp32 block): K = 8 (one group), only p < OUT non-zero
+  const char* cur = cs.publish(CB::BLAST);
+  mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
+  mask_out(NS::NL - 1);
+  const char* lane_base = cs.publish(CB::HID) + lane_off;
+
+#pragma unroll 1
+  for (int l = NS::NL - 2; l >= 1; --l) {
+    bf_enter(pp, in, lane_base);
+    // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
+    bf_block<true>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), hook_store);
+    mask_out(l);
+  }
+  lane_base -= lane_off;
+
+  if constexpr (NS::DX0) {
+    // dPE = W_0^T dZ_0  (M = 64 padded PE features, K = 256) in two 16-group halves, then through sin/cos to the 2-D input
+    static_assert(NS::IN == AF_IN_PE2, "input gradient is only needed for the atlas net");
+    f32x16 acc2[2];
+    mm_block<2, 16, 0, 4, true>(acc2, in, lane_base + (h * 64 + j) * 16, hook_dma_store);
+    const char* half2 = cs.publish(CB::BL0H);
+    mm_block<2, 16, 64, 4>(acc2, in, half2 + (h * 64 + j) * 16, hook_dma);
+    const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+    float dx0 = 0.f, dx1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+      float pv[4], dv[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        pv[p] = af_bl32(r, (4 * h * 32 + j) * 4, (8 * g + p) * 128);
+        dv[p] = acc2[g >> 2][(g & 3) * 4 + p];
+      }
+      const float b = h ? __builtin_ldexpf(3.14159265358979323846f, 2 * g + 1) : __builtin_ldexpf(3.14159265358979323846f, 2 * g);
+      dx0 += b * (pv[2] * dv[0] - pv[0] * dv[2]);
+      dx1 += b * (pv[3] * dv[1] - pv[1] * dv[3]);
+    }
+    dx0 += __shfl_xor(dx0, 32);
+    dx1 += __shfl_xor(dx1, 32);
+    if (live && h == 0 && row < a.nrows) {
+      float* dst = row < a.split_row ? a.din0 + (size_t)row * 4 : a.din1 + (size_t)(row - a.split_row) * 4;
+      dst[0] += a.din_scale * dx0;
+      dst[1] += a.din_scale * dx1;
+    }
+  } else {
+    // dZ_0 of a net whose input needs no gradient: nothing left to hide the stores behind
+    ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
+    ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0, base = 0;
+  const int wg = blockIdx.x;
+  while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
+  switch (m.net[s]) {
+    case AF_NET_MAP1:  mlp_fwd_body_bf<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  mlp_fwd_body_bf<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: mlp_fwd_body_bf<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
+    default:           mlp_fwd_body_bf<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0, base = 0;
+  const int wg = blockIdx.x;
+  while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
+  switch (m.net[s]) {
+    case AF_NET_MAP1:  mlp_bwd_body_bf<NsMap1>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  mlp_bwd_body_bf<NsMap2>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: mlp_bwd_body_bf<NsAtlas>(m.a[s], wg - base, smem); break;
+    default:           mlp_bwd_body_bf<NsAlpha>(m.a[s], wg - base, smem); break;
+  }
+}
+
+extern "C" int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s) {
+  int tot = 0;
+  for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
+  if (tot <= 0) return 0;
+  if (train) hipLaunchKernelGGL((k_mlp_fwd_multi_bf<true>), dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
+  else       hipLaunchKernelGGL((k_mlp_fwd_multi_bf<false>), dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
+  return (int)hipGetLastError();
+}
+extern "C" int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s) {
+  int tot = 0;
+  for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(k_mlp_bwd_multi_bf, dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
+  return (int)hipGetLastError();
+}
+// chunk sizes of the bf16 streams for the host planner: which = 0 fwd layer 0, 1 bf16 hidden chunk (x8 per layer), 2 skip columns,
+// 3 fwd output layer, 4 bwd output layer, 5 half of bwd layer 0 (x2)
+extern "C" int af_mlp_chunk_bytes_bf(int net, int which) {
+  auto pick = [&](auto ns) -> int {
+    using CB = ChunkBytesBf<decltype(ns)>;
+    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::LAST, CB::BLAST, CB::BL0H};
+    return which >= 0 && which < 6 ? v[which] : -1;
+  };
+  switch (net) {
+    case AF_NET_MAP1:  return pick(NsMap1{});
+    case AF_NET_MAP2:  return pick(NsMap2{});
+    case AF_NET_ATLAS: return pick(NsAtlas{});
+    case AF_NET_ALPHA: return pick(NsAlpha{});
+    default: return -1;
+  }
+}
+extern "C" int af_mlp_bf_init() {
+  hipError_t e = hipSuccess;
+#define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES_BF); if (r != hipSuccess) e = r; } while (0)
+  AF_ATTR((k_mlp_fwd_multi_bf<true>)); AF_ATTR((k_mlp_fwd_multi_bf<false>)); AF_ATTR(k_mlp_bwd_multi_bf);
+#undef AF_ATTR
+  return (int)e;
+}

@@ -25,51 +25,68 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # ---------------------------------------------------------------------------------------------
 # input builder (unwrap_utils.py)
+def _linear_coeffs(src, dst):
+    """OpenCV resize.cpp, INTER_LINEAR: first tap and the two FLOAT coefficients per destination index:
+    f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s; taps outside clamp with weight 1."""
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * (float(src) / float(dst)) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= src - 1
+    s[lo] = 0; f[lo] = 0.0
+    s[hi] = src - 1; f[hi] = 0.0
+    return s, np.minimum(s + 1, src - 1), (np.float32(1.0) - f).astype(np.float32), f
+
+
 def resize_bilinear(img, new_w, new_h):
-    """cv2.resize(img, (new_w, new_h)) with the default INTER_LINEAR: half-pixel centres, edge clamping,
-    no anti-aliasing.  img: (H, W[, C]) float array."""
+    """cv2.resize(img, (new_w, new_h)) with the default INTER_LINEAR, in OpenCV's arithmetic: half-pixel centres, edge
+    clamping, no anti-aliasing, float32 interpolation coefficients, horizontal pass then vertical pass in the image's
+    own precision (double for the float64 frames / masks, float for the float32 flows).  img: (H, W[, C]) float array."""
     img = np.asarray(img)
+    if img.dtype not in (np.float32, np.float64):
+        img = img.astype(np.float64)
     h, w = img.shape[:2]
     if (h, w) == (new_h, new_w):
         return img.copy()
-    sx, sy = w / new_w, h / new_h
-    fx = (np.arange(new_w, dtype=np.float64) + 0.5) * sx - 0.5
-    fy = (np.arange(new_h, dtype=np.float64) + 0.5) * sy - 0.5
-    x0 = np.floor(fx).astype(np.int64); y0 = np.floor(fy).astype(np.int64)
-    ax = (fx - x0); ay = (fy - y0)
-    x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
-    y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
-    if img.ndim == 3:
-        ax_, ay_ = ax[None, :, None], ay[:, None, None]
-    else:
-        ax_, ay_ = ax[None, :], ay[:, None]
-    top = img[y0c][:, x0c] * (1 - ax_) + img[y0c][:, x1c] * ax_
-    bot = img[y1c][:, x0c] * (1 - ax_) + img[y1c][:, x1c] * ax_
-    return (top * (1 - ay_) + bot * ay_).astype(img.dtype)
+    wt = img.dtype.type
+    sx, sx1, a0, a1 = _linear_coeffs(w, new_w)
+    sy, sy1, b0, b1 = _linear_coeffs(h, new_h)
+    shp = (1, new_w) + (1,) * (img.ndim - 2)
+    a0, a1 = a0.astype(wt).reshape(shp), a1.astype(wt).reshape(shp)
+    top = img[sy][:, sx] * a0 + img[sy][:, sx1] * a1
+    bot = img[sy1][:, sx] * a0 + img[sy1][:, sx1] * a1
+    shp = (new_h, 1) + (1,) * (img.ndim - 2)
+    return (top * b0.astype(wt).reshape(shp) + bot * b1.astype(wt).reshape(shp)).astype(img.dtype)
 
 
 def resize_flow(flow, newh, neww):
     """unwrap_utils.py:33-38 (u is scaled by newh/oldh and v by neww/oldw, as the reference does)."""
     oldh, oldw = flow.shape[0:2]
     flow = resize_bilinear(flow.astype(np.float32), neww, newh)
-    flow[:, :, 0] *= newh / oldh
-    flow[:, :, 1] *= neww / oldw
+    flow[:, :, 0] *= np.float32(newh / oldh)
+    flow[:, :, 1] *= np.float32(neww / oldw)
     return flow
 
 
 def _remap_bilinear_zero(img, mapx, mapy):
-    """cv2.remap(img, map, None, INTER_LINEAR), constant-0 border (unwrap_utils.py:22)."""
+    """cv2.remap(img, map, None, INTER_LINEAR), constant-0 border (unwrap_utils.py:22), in OpenCV's arithmetic: the
+    float map is converted to fixed point with INTER_BITS = 5 (cvRound(x * 32), half to even) — positions are quantised
+    to 1/32 px — and the four taps are blended with the table weights in float32, left to right."""
     h, w = img.shape[:2]
-    x0 = np.floor(mapx).astype(np.int64); y0 = np.floor(mapy).astype(np.int64)
-    fx = (mapx - x0).astype(np.float32)[..., None]; fy = (mapy - y0).astype(np.float32)[..., None]
+    qx = np.rint(mapx.astype(np.float32) * np.float32(32)).astype(np.int64)
+    qy = np.rint(mapy.astype(np.float32) * np.float32(32)).astype(np.int64)
+    x0, y0 = qx >> 5, qy >> 5
+    fx = ((qx & 31).astype(np.float32) / np.float32(32))[..., None]
+    fy = ((qy & 31).astype(np.float32) / np.float32(32))[..., None]
+    one = np.float32(1.0)
 
     def tap(yy, xx):
         ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
         v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
         return np.where(ok[..., None], v, 0.0).astype(np.float32)
 
-    return (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy)
-            + tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
+    return ((tap(y0, x0) * ((one - fy) * (one - fx)) + tap(y0, x0 + 1) * ((one - fy) * fx))
+            + tap(y0 + 1, x0) * (fy * (one - fx))) + tap(y0 + 1, x0 + 1) * (fy * fx)
 
 
 def compute_consistency(flow12, flow21):
@@ -231,7 +248,8 @@ def _torch_module(net, sd):
     import torch
     from .atlasfit import imlp_shapes
     m = torch.nn.Module()
-    m.hidden = torch.nn.ModuleList([torch.nn.Linear(k, o) for (o, k) in imlp_shapes(net)])
+    m.hidden = torch.nn.ModuleList([torch.nn.Linear(int(np.asarray(sd["hidden.%d.weight" % i]).shape[1]), int(np.asarray(sd["hidden.%d.weight" % i]).shape[0]))
+                                    for i in range(len(sd) // 2)])
     m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
     return m
 
@@ -268,7 +286,7 @@ def load_checkpoint(af, path):
     idx, step = 0, 0
     for _, net in layout:
         ms, vs = [], []
-        for (o, k) in imlp_shapes(net):
+        for (o, k) in imlp_shapes(net, af.cfg):
             for _ in range(2):               # weight, bias
                 s = st[idx]; idx += 1
                 ms.append(s["exp_avg"].reshape(-1).numpy()); vs.append(s["exp_avg_sq"].reshape(-1).numpy()); step = int(s["step"])
@@ -331,28 +349,35 @@ def main(config, args, two_layer=False):
     F = video_frames.shape[3]
     af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=getattr(args, "device_ordinal", 0))
     af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask, mask_frames)
+    import math
     import torch
+    # Random draws: the reference uses torch's process-global RNG.  With --seed (an extension) every draw of this call comes
+    # from its own torch.Generator, so concurrent videos in one process (launch_videos.py --concurrent) stay reproducible
+    # and independent; without it the global RNG is used like the reference does.
     seed = getattr(args, "seed", None)
-    if seed is not None:
-        torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+    draw = lambda: int(torch.randint(2 ** 31, (1,), generator=gen))
     start_iteration = 0
     if not config["load_checkpoint"]:
         # nn.Linear default init in the reference's construction order (:112-128; seg :127-161 mapping1, mapping2, atlas, alpha)
         order = (A.NET_MAPPING1, A.NET_MAPPING2, A.NET_ATLAS, A.NET_ALPHA) if two_layer else (A.NET_MAPPING1, A.NET_ATLAS)
         for net in order:
             sd = {}
-            for i, (o, k) in enumerate(A.imlp_shapes(net)):
-                lin = torch.nn.Linear(k, o)
-                sd["hidden.%d.weight" % i] = lin.weight.detach(); sd["hidden.%d.bias" % i] = lin.bias.detach()
+            for i, (o, k) in enumerate(A.imlp_shapes(net, af.cfg)):
+                w, b = torch.empty(o, k), torch.empty(o)
+                torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5), generator=gen)          # nn.Linear.reset_parameters
+                bound = 1 / math.sqrt(k)
+                torch.nn.init.uniform_(b, -bound, bound, generator=gen)
+                sd["hidden.%d.weight" % i] = w; sd["hidden.%d.bias" % i] = b
             af.load_state_dict(net, sd)
         if config["pretrain_mapping1"]:
             print("pre-training")
-            af.pre_train_mapping(config["pretrain_iter_number"], seed=int(torch.randint(2 ** 31, (1,))))
+            af.pre_train_mapping(config["pretrain_iter_number"], seed=draw())
         if two_layer and config["pretrain_mapping2"]:
-            af.pre_train_mapping(config["pretrain_iter_number"], seed=int(torch.randint(2 ** 31, (1,))), net=A.NET_MAPPING2)
+            af.pre_train_mapping(config["pretrain_iter_number"], seed=draw(), net=A.NET_MAPPING2)
     else:
         start_iteration = load_checkpoint(af, config["checkpoint_path"])
-    sampler_seed = int(torch.randint(2 ** 31, (1,)))
+    sampler_seed = draw()
     i = start_iteration
     last_psnr = None
     while i < iters_num:
@@ -401,8 +426,18 @@ def _cli(argv=None, two_layer=False):
     parser.add_argument("--skip_preprocess", action="store_true", help="(extension) do not call the reference's flow / mask preprocessors even if ./src has them")
     parser.add_argument("--host_loader", action="store_true", help="(extension) build the input tensors with the numpy loader instead of the device one")
     args = parser.parse_args(argv)
-    os.environ["CUDA_VISIBLE_DEVICES"] = "%d" % args.gpu        # reference :267-268 (HIP honours it on ROCm)
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", "%d" % args.gpu)
+    # reference :267-268 sets CUDA_VISIBLE_DEVICES.  On ROCm HIP_VISIBLE_DEVICES takes precedence: when the scheduler / user
+    # already restricted the visible GPUs, --gpu indexes into that list; both variables end up naming the one chosen device
+    # (also for the preprocessor subprocesses).
+    preset = [p for p in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if p.strip() != ""]
+    if preset:
+        if args.gpu >= len(preset):
+            raise SystemExit("--gpu %d but HIP_VISIBLE_DEVICES=%s lists only %d device(s)" % (args.gpu, os.environ["HIP_VISIBLE_DEVICES"], len(preset)))
+        chosen = preset[args.gpu].strip()
+    else:
+        chosen = "%d" % args.gpu
+    os.environ["CUDA_VISIBLE_DEVICES"] = chosen
+    os.environ["HIP_VISIBLE_DEVICES"] = chosen
     args.device_ordinal = 0
     args.vid_path = os.path.join(args.root, args.vid_name)
     _run_reference_preprocessors(args, two_layer)

@@ -20,6 +20,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured for a streaming copy)
+METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs ref"     # BASELINE.json "metric"
+# launch classes of af_get_timing -> kernel names as rocprofv3 prints them
+KERNEL_OF_CLASS = {"fwd_1": "k_mlp_fwd_multi<true>", "fwd_2": "k_mlp_fwd_multi<true>", "bwd_1": "k_mlp_bwd_multi", "bwd_2": "k_mlp_bwd_multi",
+                   "dw": "k_dw_bf", "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
 
 
 def synth_video_device(resx, resy, nframes, seed, device):
@@ -178,6 +183,8 @@ def main():
     ap.add_argument("--videos-per-gpu", type=int, default=1, help="(a different workload from the headline one) V independent videos per GPU, "
                     "optimised concurrently from V host threads on V streams: the kernels of one fill the idle tail rounds of the others")
     ap.add_argument("--first-iter", type=int, default=-1, help="first timed iteration (default: K steps centred on the global-rigidity switch at 5000/5001)")
+    ap.add_argument("--valid-fraction", type=float, default=1.0, help="keep this fraction of the (synthetic, ~0.98 valid) flow-consistency masks, chosen at random "
+                    "per pixel: real RAFT masks are far from all-valid, and only valid rows are credited as algorithmic work (loss_utils.py:326-356)")
     args = ap.parse_args()
 
     import torch
@@ -199,6 +206,9 @@ def main():
     af = aiod_amd.AtlasFit(cfg, device=local)
     vseed = shard_for_rank(rank, world)[0]
     video = synth_video_device(args.resx, args.resy, args.frames, seed=vseed, device=dev)
+    if args.valid_fraction < 1.0:
+        gm = torch.Generator(device=dev).manual_seed(97 + vseed)
+        video = video[:3] + tuple(m * (torch.rand(m.shape, device=dev, generator=gm) < args.valid_fraction).float() for m in video[3:5])
     if args.two_layer:
         video = video + (synth_fg_mask_device(args.resx, args.resy, args.frames, seed=vseed, device=dev),)
     af.upload_video(*video)
@@ -226,8 +236,15 @@ def main():
     if W > 0:
         af.train_steps(wfirst, W, None, seed=rank, return_losses=False)
     tw = af.timing(reset=True)
-    dom = max(classes, key=lambda c: tw[c][0]) if W > 0 else "dw"
-    af.set_timing(1 << classes.index(dom))                         # events only around the dominant kernel
+    # the dominant KERNEL (by name, all of its launches in a step: k_mlp_fwd_multi = fwd_1 + fwd_2, ...), not the dominant launch
+    by_name = {}
+    for c in classes:
+        by_name.setdefault(KERNEL_OF_CLASS[c], []).append(c)
+    if os.environ.get("AF_DW_FP32"):
+        by_name["k_dw"] = by_name.pop("k_dw_bf")
+    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else ("k_dw" if "k_dw" in by_name else "k_dw_bf")
+    dom_classes = by_name[dom]
+    af.set_timing(sum(1 << classes.index(c) for c in dom_classes))   # events only around the dominant kernel's launches
 
     # ---- optional extra videos on this GPU (own handle, stream, weights, table), warmed like the first
     extra = []
@@ -274,22 +291,33 @@ def main():
 
     # ---- roofline of the dominant kernel: algorithmic FLOPs per launch (accumulated by the library from the rows each
     # launch covered) / mean HIP-event duration over the timed region
-    dom_ms = tk[dom][0] / max(tk[dom][1], 1)
-    flops_launch = (tk[dom][2] - (masked_dw_flops if dom == "dw" else 0.0)) / max(tk[dom][1], 1)
+    n_launch = max(sum(tk[c][1] for c in dom_classes), 1)
+    dom_ms = sum(tk[c][0] for c in dom_classes) / n_launch
+    is_dw = "dw" in dom_classes
+    # masked flow rows inside the MLP launches: fwd / dX work of rows the reference would not evaluate (all in the mapping nets + alpha)
+    masked_mlp = inv * (sum(FWD[n] for n in nets_inv) if dom.startswith("k_mlp_fwd") else sum(DX[n] for n in nets_inv)) if not is_dw else 0.0
+    flops_launch = (sum(tk[c][2] for c in dom_classes) - (masked_dw_flops if is_dw else masked_mlp)) / n_launch
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
+    # every hot kernel by name (warm-up pass, all launch classes timed): ms per step, TFLOP/s, fraction of the FP32-MFMA peak
+    by_kernel = {}
+    for kname, cls in by_name.items():
+        ms = sum(tw[c][0] for c in cls); fl = sum(tw[c][2] for c in cls); nl = sum(tw[c][1] for c in cls)
+        if ms > 0 and W > 0:
+            by_kernel[kname] = {"ms_per_step": ms / W, "launches_per_step": nl / W, "tflops": (fl / ms / 1e9) if fl > 0 else None,
+                                "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None}
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of
     # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
     # quoted when it covers this kernel and workload, else null.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r1c_traffic.json")
-    kname = {"dw": "k_dw", "fwd_1": "k_mlp_fwd_multi<true>", "fwd_2": "k_mlp_fwd_multi<true>", "bwd_1": "k_mlp_bwd_multi", "bwd_2": "k_mlp_bwd_multi"}.get(dom)
+    tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    kname = dom
     if os.path.exists(tpath) and not args.two_layer and (args.resx, args.resy, args.frames) == (768, 432, 80) and args.first_iter < 0:
         try:
             tj = json.load(open(tpath))
             traffic = tj["kernels"][kname]["hbm_bytes"]
-            traffic_src = "profiles/r1c_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
+            traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
         except Exception:
             traffic = None
 
@@ -298,7 +326,7 @@ def main():
         V = 1 + len(extra)
         value = world * V * N * K / dt
         out = {
-            "metric": "atlas-fit sampled points/sec (stage1 main loop)", "value": value, "unit": "sampled points/s",
+            "metric": METRIC, "value": value, "unit": "sampled points/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
@@ -309,9 +337,10 @@ def main():
                        "videos_per_gpu": V,
                        "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
             "pretrain_ms_per_step": pre_ms,
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": dom, "kernel_launch_classes": dom_classes, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                         "kernel_ms": dom_ms, "flops_per_launch": flops_launch,
+                         "kernel_ms": dom_ms, "flops_per_launch": flops_launch, "launches_per_step": n_launch / K,
+                         "by_kernel": by_kernel,
                          "valid_flow_fraction": float(nv.sum() / (2.0 * N * K)),
                          "whole_step_tflops": V * total_flops / dt / 1e12, "whole_step_frac": V * total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes},

@@ -139,6 +139,9 @@ int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
  * bf16 matrix pipe; 0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Both carry fp32-level round-off
  * (tests/test_split_precision.py, tests/test_gpu_dw_modes.py); mode 0 is kept as the cross-check.  Env AF_DW_FP32=1 selects 0. */
 int af_set_dw_mode(af_handle* h, int mode);
+/* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
+ * = bf16x6, 0 = fp32 matrix pipe.  Env AF_MLP_FP32=1 selects 0.  pre_train_mapping always runs the fp32 16-row chains. */
+int af_set_mlp_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);

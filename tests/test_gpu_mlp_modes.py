@@ -1,0 +1,70 @@
+"""The 256x256 hidden-layer products of the forward / backward chains run either on the fp32 matrix pipe (mode 0,
+mlp.hip) or fp32-faithfully on the bf16 matrix pipe (mode 1, the default; mlpbf.hip: weights pre-split into three bf16
+images by k_adam, activations split in registers, six partial products per product).  Same nets, same rows: forward
+outputs, loss terms and reduced gradients of the two modes must agree to fp32 round-off."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(af, two_layer, seed=7):
+    import aiod_amd
+    import bench
+    sds = bench.init_state_dicts(seed, two_layer)
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    af.pre_train_mapping(2, seed=3)
+    if two_layer:
+        af.pre_train_mapping(2, seed=4, net=aiod_amd.NET_MAPPING2)
+    return {net: af.state_dict(net) for net in af.nets}
+
+
+@pytest.mark.parametrize("two_layer", [False, True])
+def test_mlp_modes_agree_at_full_size(two_layer):
+    import aiod_amd
+    import bench
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 80
+    video = bench.synth_video_device(resx, resy, F, seed=5, device=dev)
+    if two_layer:
+        video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=5, device=dev),)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=two_layer))
+    af.upload_video(*video)
+    sds = _state(af, two_layer)
+    g = torch.Generator().manual_seed(13)
+    rows = np.zeros((4096, 4), np.float32); rows[:, :3] = torch.rand(4096, 3, generator=g).numpy() * 2 - 1
+    fw = {}
+    for mode in (0, 1):
+        af.set_mlp_mode(mode)
+        fw[mode] = {net: af.debug_forward(net, rows) for net in af.nets}
+    for net in af.nets:
+        d = np.abs(fw[1][net] - fw[0][net]).max()
+        print("two_layer", two_layer, "net", net, "forward max |bf16x6 - fp32 MFMA| %.3g" % d)
+        assert d < 3e-6, (net, d)
+    for it in (0, 6000):
+        inds = torch.randint(F * resx * resy, (af.N,), generator=g).numpy()
+        res = {}
+        for mode in (0, 1):
+            af.set_mlp_mode(mode)
+            for net in af.nets:
+                af.load_state_dict(net, sds[net])
+                z = np.zeros(af.param_count(net), np.float32)
+                af.set_adam_state(net, z, z, 0)
+            af.set_debug(True)
+            losses = af.train_steps(it, 1, inds)[0]
+            res[mode] = (losses.copy(), {net: af.last_grads(net) for net in af.nets})
+        n = 12 if two_layer else 6
+        rel = np.abs(res[1][0][:n] - res[0][0][:n]) / np.maximum(np.abs(res[0][0][:n]), 1e-9)
+        print("iter", it, "loss terms rel", rel.max())
+        assert rel.max() < 2e-5, (it, res[1][0], res[0][0])
+        for net in af.nets:
+            g0, g1 = res[0][1][net], res[1][1][net]
+            r = np.linalg.norm(g1 - g0) / np.linalg.norm(g0)
+            print("iter", it, "net", net, "gradient rel (L2) bf16x6 vs fp32 MFMA chains %.3g" % r)
+            assert r < 1e-3, (it, net, r)      # forward differences of ~2e-7 in uv are amplified by the finite-difference rigidity terms
+    af.set_mlp_mode(1)
+    af.close()
+    del video
+    torch.cuda.empty_cache()

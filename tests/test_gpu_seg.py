@@ -88,7 +88,8 @@ def test_forward_mapping2_and_alpha_match_reference_imlp(af, golden_seg):
 def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_seg_video):
     """First loop iteration from the fixture's start state (both mapping nets pre-trained by the reference's
     pre_train_mapping): all 12 loss terms and the four nets' gradients against the values the reference's own
-    modules produced (oracle/make_golden_seg.py).  Strict: 1e-4 on the terms, 1e-3 on the gradients."""
+    modules produced (oracle/make_golden_seg.py).  Strict 1e-4 on the terms; gradients within 1e-3 of the reference's,
+    plus the reference's own distance from an fp64 twin where that is larger."""
     from conftest import seg_start_models
     from oracle import atlas_oracle as O
     models = seg_start_models(golden_seg)
@@ -116,7 +117,10 @@ def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_s
         e_ref = np.linalg.norm(ref_s - s64) / np.linalg.norm(s64)
         e_hr = np.linalg.norm(g[::97] - ref_s) / np.linalg.norm(ref_s)
         print("net", k, "grad error vs fp64: hip %.3g  reference-fp32 %.3g  hip-vs-reference %.3g" % (e_hip, e_ref, e_hr))
-        assert e_hr < 1e-3, (k, e_hr, e_hip, e_ref)
+        # within 1e-3 of the reference's gradient, widened only by the reference's OWN fp32 error on this net (the atlas
+        # net's gradient from 256 samples is 3e-3 off its fp64 value in torch-fp32 — the bf16x6 chains are 6e-5 off)
+        assert e_hr < 1e-3 + 1.05 * e_ref, (k, e_hr, e_hip, e_ref)
+        assert e_hip < 1e-3 + 1.05 * e_ref, (k, e_hip, e_ref)
 
 
 def test_trajectory_psnr_and_parameters_match_reference(af, golden_seg, small_seg_video):

@@ -112,3 +112,19 @@ def test_pe_slot_permutations_are_injective():
     assert [pe_slot_of_feature(1, e) for e in range(40)] == list(range(40))
     slots = [pe_slot_of_feature(2, e) for e in range(30)]
     assert len(set(slots)) == 30 and max(slots) < 32
+
+
+def test_imlp_shapes_follow_the_config_and_match_the_reference_counts():
+    """atlasfit.imlp_shapes derives the layer shapes from the AfConfig: the shipped config gives the reference's
+    parameter counts, a different architecture gives different shapes (which AtlasFit.__init__ then refuses
+    against the library's own count before anything reaches the C side)."""
+    import aiod_amd
+    A = aiod_amd.atlasfit
+    cfg = A.default_config(64, 48, 4, two_layer=True)
+    counts = {net: sum(o * k + o for o, k in A.imlp_shapes(net, cfg)) for net in (A.NET_MAPPING1, A.NET_ATLAS, A.NET_MAPPING2, A.NET_ALPHA)}
+    assert counts == {A.NET_MAPPING1: 264706, A.NET_ATLAS: 416379, A.NET_MAPPING2: 133122, A.NET_ALPHA: 402945}
+    assert A.imlp_shapes(A.NET_ATLAS, cfg) == A.imlp_shapes(A.NET_ATLAS)            # the defaults are the shipped architecture
+    assert A.imlp_shapes(A.NET_ATLAS, cfg)[4] == (256, 296) and A.imlp_shapes(A.NET_ATLAS, cfg)[7] == (3, 296)
+    other = A.default_config(64, 48, 4, number_of_channels_atlas=128, number_of_layers_mapping1=4, positional_encoding_num_atlas=6)
+    assert A.imlp_shapes(A.NET_ATLAS, other)[0] == (128, 24) and len(A.imlp_shapes(A.NET_MAPPING1, other)) == 4
+    assert sum(o * k + o for o, k in A.imlp_shapes(A.NET_ATLAS, other)) != 416379

@@ -143,42 +143,94 @@ def test_two_layer_cli_results_tree_checkpoint_and_resume(tmp_path, small_seg_vi
     af.close()
 
 
-@pytest.mark.gpu
-def test_device_input_builder_matches_host_restatement(tmp_path, small_seg_video):
-    """af_resize_bilinear / af_flow_consistency (the device side of load_input_data, unwrap_utils.py:40-163) against the
-    numpy restatement: frames and masks stored at twice the working resolution (so the bilinear resize runs), flows
-    stored at another resolution (resize_flow's rescaling) and perturbed so that the consistency mask is non-trivial."""
-    import torch
-    import aiod_amd.stage1 as S
+def _write_builder_case(tmp_path, v, seed=2):
+    """Frames and masks stored at twice the working resolution (so the bilinear resize runs), flows stored at another
+    resolution (resize_flow's rescaling) and perturbed so that the consistency mask is non-trivial."""
     from PIL import Image
-    v = small_seg_video
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(seed)
     d = tmp_path / "clip"; d.mkdir(); fd = tmp_path / "clip_flow"; fd.mkdir(); sd = tmp_path / "clip_seg"; sd.mkdir()
     H2, W2 = 2 * v.resy, 2 * v.resx
     names = ["%05d.png" % f for f in range(v.F)]
+    imgs, masks, flows = [], [], []
     for f in range(v.F):
-        Image.fromarray(rng.integers(0, 256, (H2, W2, 3), dtype=np.uint8)).save(str(d / names[f]))
-        Image.fromarray(rng.integers(0, 256, (H2, W2), dtype=np.uint8)).save(str(sd / names[f]))
+        im = rng.integers(0, 256, (H2, W2, 3), dtype=np.uint8); mk = rng.integers(0, 256, (H2, W2), dtype=np.uint8)
+        Image.fromarray(im).save(str(d / names[f])); Image.fromarray(mk).save(str(sd / names[f]))
+        imgs.append(im); masks.append(mk)
     fh, fw = v.resy + 8, v.resx + 16                                  # RAFT's padded resolution differs from the frames'
     for f in range(v.F - 1):
         f12 = (rng.standard_normal((fh, fw, 2)) * 1.5).astype(np.float32)
         f21 = (-f12 + rng.standard_normal((fh, fw, 2)) * 0.6).astype(np.float32)
         np.save(fd / ("%s_%s.npy" % (names[f], names[f + 1])), f12); np.save(fd / ("%s_%s.npy" % (names[f + 1], names[f])), f21)
+        flows.append((f12, f21))
+    return d, imgs, masks, flows
+
+
+def _oracle_builder(v, imgs, masks, flows):
+    """load_input_data (unwrap_utils.py:40-163) with its two OpenCV calls taken from oracle/cv_oracle.py (the restatement of
+    cv2.resize / cv2.remap pinned by tests/test_cv_oracle.py)."""
+    from oracle import cv_oracle as C
+    F = v.F
+    frames = np.zeros((v.resy, v.resx, 3, F), np.float32); mk = np.zeros((v.resy, v.resx, F), np.float32)
+    fl = np.zeros((v.resy, v.resx, 2, F), np.float32); fr = np.zeros_like(fl)
+    m = np.zeros((v.resy, v.resx, F), np.float32); mr = np.zeros_like(m)
+    for i in range(F):
+        frames[:, :, :, i] = C.cv_resize_linear(imgs[i].astype(np.float64) / 255.0, v.resx, v.resy)
+        mk[:, :, i] = C.cv_resize_linear(masks[i].astype(np.float64) / 255.0, v.resx, v.resy)
+    for i in range(F - 1):
+        f12 = C.cv_resize_flow(flows[i][0], v.resy, v.resx); f21 = C.cv_resize_flow(flows[i][1], v.resy, v.resx)
+        fl[:, :, :, i] = f12; fr[:, :, :, i + 1] = f21
+        m[:, :, i] = C.cv_compute_consistency(f12, f21) < 1.0
+        mr[:, :, i + 1] = C.cv_compute_consistency(f21, f12) < 1.0
+    return frames, mk, fl, fr, m, mr
+
+
+def test_host_input_builder_equals_opencv_restatement(tmp_path, small_seg_video):
+    """The numpy loader of the product (stage1.load_input_data_single / load_mask_frames) is bit-identical to the loader
+    assembled from the oracle's OpenCV restatement: float32 resize coefficients, 1/32-px remap positions."""
+    import aiod_amd.stage1 as S
+    v = small_seg_video
+    d, imgs, masks, flows = _write_builder_case(tmp_path, v)
     hm, hf, hmr, hfr, hfl = S.load_input_data_single(v.resy, v.resx, 200, d, True, tmp_path, "clip")
     hmask = S.load_mask_frames(v.resy, v.resx, v.F, tmp_path, "clip")
+    frames, mk, fl, fr, m, mr = _oracle_builder(v, imgs, masks, flows)
+    assert np.array_equal(hf, frames) and np.array_equal(hmask, mk)
+    assert np.array_equal(hfl[..., 0], fl) and np.array_equal(hfr[..., 0], fr)
+    assert np.array_equal(hm[..., 0], m) and np.array_equal(hmr[..., 0], mr)
+    assert 0.02 < m[:, :, :-1].mean() < 0.98                              # a non-trivial mask
+    # the 1/32-px quantisation matters: an exact-fraction bilinear warp flips pixels of this mask
+    f12, f21 = fl[:, :, :, 0], fr[:, :, :, 1]
+    x = f12[:, :, 0] + np.arange(v.resx, dtype=np.float32); y = f12[:, :, 1] + np.arange(v.resy, dtype=np.float32)[:, None]
+    x0 = np.floor(x).astype(int); y0 = np.floor(y).astype(int); fx = (x - x0)[..., None]; fy = (y - y0)[..., None]
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < v.resx) & (yy >= 0) & (yy < v.resy)
+        return np.where(ok[..., None], f21[np.clip(yy, 0, v.resy - 1), np.clip(xx, 0, v.resx - 1)], 0.0)
+    wexact = tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) + tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy
+    dd = f12 + wexact
+    print("pixels whose consistency bit differs between exact-fraction and 1/32-px remap:", int(((np.sqrt((dd ** 2).sum(-1)) < 1.0) != (m[:, :, 0] > 0)).sum()))
+
+
+@pytest.mark.gpu
+def test_device_input_builder_equals_opencv_restatement(tmp_path, small_seg_video):
+    """af_resize_bilinear / af_flow_consistency (k_resize_bilinear / k_flow_consistency, the device side of load_input_data,
+    unwrap_utils.py:40-163) against the oracle's restatement of cv2.resize / cv2.remap: bit-identical tensors — frames,
+    fractional fg masks, rescaled flows and both consistency masks (no pixel may flip)."""
+    import torch
+    import aiod_amd.stage1 as S
+    from oracle import cv_oracle as C
+    v = small_seg_video
+    d, imgs, masks, flows = _write_builder_case(tmp_path, v)
+    frames, mk, fl, fr, m, mr = _oracle_builder(v, imgs, masks, flows)
     dm, df, dmr, dfr, dfl, dmask = [t.cpu().numpy() for t in S.load_input_data_device(v.resy, v.resx, 200, d, True, tmp_path, "clip", with_masks=True)]
-    assert np.abs(df - hf).max() < 1e-6 and np.abs(dmask - hmask).max() < 1e-6
-    assert np.abs(dfl - hfl[..., 0]).max() < 1e-5 and np.abs(dfr - hfr[..., 0]).max() < 1e-5
-    for a, b in ((dm, hm[..., 0]), (dmr, hmr[..., 0])):
-        assert 0.02 < b.mean() < 0.98                                     # a non-trivial mask
-        assert (a != b).mean() < 1e-3                                     # only pixels whose norm sits on the threshold may flip
-    # the norm field itself, on the host-resized flows
-    f12 = torch.from_numpy(np.ascontiguousarray(hfl[:, :, :, 0, 0])).cuda(); f21 = torch.from_numpy(np.ascontiguousarray(hfr[:, :, :, 1, 0])).cuda()
+    assert np.array_equal(df, frames) and np.array_equal(dmask, mk)
+    assert np.array_equal(dfl, fl) and np.array_equal(dfr, fr)
+    assert np.array_equal(dm, m) and np.array_equal(dmr, mr)
+    # the norm field itself
+    f12 = torch.from_numpy(np.ascontiguousarray(fl[:, :, :, 0])).cuda(); f21 = torch.from_numpy(np.ascontiguousarray(fr[:, :, :, 1])).cuda()
     out = torch.empty(v.resy, v.resx, device="cuda")
     aiod = __import__("aiod_amd")
     aiod.atlasfit.flow_consistency_device(f12, f21, out, 1, 0, thresh=0.0)
-    ref = S.compute_consistency(hfl[:, :, :, 0, 0], hfr[:, :, :, 1, 0])
-    assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
+    ref = C.cv_compute_consistency(fl[:, :, :, 0], fr[:, :, :, 1])
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1.2e-7 * np.abs(ref).max()      # (x ** .5 is powf in numpy, sqrtf on the device: <= 1 ulp)
 
 
 @pytest.mark.gpu
