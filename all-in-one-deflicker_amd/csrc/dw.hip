@@ -24,21 +24,12 @@
 #ifndef DW_ABL
 #define DW_ABL 0     // tools/dwbench.hip timing ablations of k_dw_bf: bit0 no operand split (raw bits fed to the MFMAs), bit1 one MFMA per
 #endif               // product instead of six, bit2 no explicit interleave (sched_group_barrier), bit3 packed-f32 subtract avoided
+#ifndef DW_STAGES
 #define DW_STAGES 4
-#define DW_LDS 131072
+#endif
+#define DW_LDS (DW_STAGES * 32768)
 
-AF_DEV void dw_wait_vm(int n) {     // n is a small compile-time-known set: keep the immediates literal
-  switch (n) {
-    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-}
+template <int N> AF_DEV void dw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // s_barrier without the release/acquire fences of __syncthreads(): a fence makes hipcc drain vmcnt to 0 in front of the
 // barrier, which is exactly what the ring avoids.  Visibility of the LDS-DMA data is given by each wave's own counted
 // vmcnt wait in front of the barrier; the "memory" clobbers keep the compiler from moving LDS reads across it.
@@ -56,7 +47,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
   constexpr int NI = (NP + 255) / 256;                   // LDS-DMA instructions per wave per stage
   constexpr int SLOT = NI * 4096;                        // ring slot (>= the stage; the tail of an odd stage is padding)
   static_assert(DW_STAGES * SLOT <= DW_LDS, "ring does not fit");
-  static_assert(NI == 2 || NI == 5 || NI == 8, "add the immediates to dw_wait_vm");
+  static_assert((DW_STAGES - 2) * NI < 64 && DW_STAGES >= 3, "vmcnt is a 6-bit counter");
   const int m = lane & 31, h = lane >> 5;
   f32x16 acc[TOW][TIW];
   float dbacc[TOW];
@@ -86,7 +77,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
   auto issue = [&](int s, int k) {                       // piece k of stage s -> ring slot s & 3
     const int sc = s < S ? s : S - 1;                    // past the end: harmless re-stage (keeps the vmcnt arithmetic uniform)
     const char* g = src[k] + (size_t)(sg.t0 + (sc >> 1)) * tstr[k] + (sc & 1) * 64;
-    af_glds16(g, smem + (s & (DW_STAGES - 1)) * SLOT + k * 4096 + wave * 1024);
+    af_glds16(g, smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
   };
 #pragma unroll
   for (int s = 0; s < DW_STAGES - 1; ++s)
@@ -128,22 +119,22 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  dw_wait_vm(2 * NI);                                    // stage 0 has landed
+  dw_wait_vm<(DW_STAGES - 2) * NI>();                                    // stage 0 has landed
   dw_barrier();
   read_frags(0, smem, 0);
   for (int s = 0; s < S; ++s) {
-    const char* slot = smem + (s & (DW_STAGES - 1)) * SLOT;
-    const char* nslot = smem + ((s + 1) & (DW_STAGES - 1)) * SLOT;
+    const char* slot = smem + (s % DW_STAGES) * SLOT;
+    const char* nslot = smem + ((s + 1) % DW_STAGES) * SLOT;
     read_frags(1, slot, 1);
     group(0);
-    dw_wait_vm(NI);                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_wait_vm<(DW_STAGES - 3) * NI>();                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
     dw_barrier();                                        // ... for every wave; and every wave is done with stage s-1
     read_frags(0, nslot, 0);                             // past the last stage: a harmless read of a re-staged slot
 #pragma unroll
     for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);
     group(1);
   }
-  dw_wait_vm(0);
+  dw_wait_vm<0>();
   dw_barrier();      // everyone done reading LDS (and the trailing re-stages landed) before the next segment restages
 
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
@@ -188,7 +179,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
   constexpr int NI = (NP + 255) / 256;
   constexpr int SLOT = NI * 4096;
   static_assert(DW_STAGES * SLOT <= DW_LDS, "ring does not fit");
-  static_assert(NI == 2 || NI == 5 || NI == 8, "add the immediates to dw_wait_vm");
+  static_assert((DW_STAGES - 2) * NI < 64 && DW_STAGES >= 3, "vmcnt is a 6-bit counter");
   const int m = lane & 31, h = lane >> 5;
   f32x16 acc[TOW][TIW];
   float dbacc[TOW];
@@ -221,7 +212,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     const char* gb = (const char*)jb.B + t * jb.b_stride * 4u + (sc & 1) * 64;
     const bool all_a = (k + 1) * 256 <= TO * 128, all_b = k * 256 >= TO * 128 && (k + 1) * 256 <= NP;
     const char* g = all_a ? ga : (all_b ? gb : (sel_a[k] ? ga : gb));
-    af_glds16(g + soff[k], smem + (s & (DW_STAGES - 1)) * SLOT + k * 4096 + wave * 1024);
+    af_glds16(g + soff[k], smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
   };
 #pragma unroll
   for (int s = 0; s < DW_STAGES - 1; ++s)
@@ -244,7 +235,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
   // fragments and the DMA of stage s+3, then column by column: the 6 x TOW products of column y run with the split of
   // column y+1 and the refresh of column y's raw registers (stage s+1) in their shadow.
   auto stage = [&](int s, int cur) {
-    const char* nslot = smem + ((s + 1) & (DW_STAGES - 1)) * SLOT;      // past the last stage: harmless reads of a re-staged slot
+    const char* nslot = smem + ((s + 1) % DW_STAGES) * SLOT;      // past the last stage: harmless reads of a re-staged slot
     DwSplit sa[TOW];
 #pragma unroll
     for (int x = 0; x < TOW; ++x) {
@@ -253,17 +244,31 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
       dbacc[x] += (t[0] + t[1]) + (t[2] + t[3]);
     }
     DwSplit sb = dw_split8(rb[0][0], rb[0][1]);
-    dw_wait_vm(NI);                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_wait_vm<(DW_STAGES - 3) * NI>();                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
     dw_barrier();                                        // ... for every wave; every wave holds what it needs of stage s-1
     read_a(cur ^ 1, nslot);
+    if constexpr (!(DW_ABL & (16 | 32))) {
 #pragma unroll
-    for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);      // into the slot stage s-1 left
+      for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);    // into the slot stage s-1 left
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int y = 0; y < TIW; ++y) {
       DwSplit sbn = sb;
       if (y + 1 < TIW) sbn = dw_split8(rb[y + 1][0], rb[y + 1][1]);
       read_b(y, nslot);                                  // column y of stage s was split one region ago: its registers take stage s+1
+      if constexpr (DW_ABL & 32) {       // evenly spread: every wave issues NI / TIW pieces per column
+#pragma unroll
+        for (int k = y * ((NI + TIW - 1) / TIW); k < (y + 1) * ((NI + TIW - 1) / TIW) && k < NI; ++k) issue(s + DW_STAGES - 1, k);
+      }
+      if constexpr (DW_ABL & 16) {
+        // staggered DMA issue: wave w pushes its share of stage s+3 during column w only, so at any time one wave of the
+        // workgroup sits in the (blocking, when HBM-bound) VMEM issue while the other three keep their matrix pipes busy
+        if ((wave % TIW) == y) {
+#pragma unroll
+          for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);
+        }
+      }
       if constexpr (!(DW_ABL & 2)) {
 #pragma unroll
         for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.l, acc[x][y]);
@@ -291,7 +296,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
       sb = sbn;
     }
   };
-  dw_wait_vm(2 * NI);                                    // stage 0 has landed
+  dw_wait_vm<(DW_STAGES - 2) * NI>();                                    // stage 0 has landed
   dw_barrier();
   read_a(0, smem);
 #pragma unroll
@@ -300,7 +305,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     stage(s, 0);
     stage(s + 1, 1);
   }
-  dw_wait_vm(0);
+  dw_wait_vm<0>();
   dw_barrier();
 
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;

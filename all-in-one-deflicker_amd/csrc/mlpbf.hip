@@ -17,6 +17,9 @@
 // holds the rest of chunk c in registers), so the next chunk's first fragments and the DMA of chunk c+2 start in the
 // shadow of chunk c's last product group.
 #include "mlp_common.h"
+#if AF_ABL & 32
+#define DW_ABL 1      // timing ablation: no operand split
+#endif
 #include "bfsplit.h"
 
 #define AF_SLOT_BF 49152
@@ -43,7 +46,7 @@ struct BfStream {
   AF_DEV void begin_stage() { p_dst = smem + (stg & 1) * AF_SLOT_BF + wave * 1024; p_it = 0; }
   AF_DEV void issue1() {
     const int k = p_it < NI ? p_it : NI - 1;
-    af_glds16(src + k * 4096, p_dst + k * 4096);
+    if constexpr (!(AF_ABL & 2)) af_glds16(src + k * 4096, p_dst + k * 4096);
     ++p_it;
   }
   AF_DEV void start(const void* img, int tid, int wave_) { src = (const char*)img + tid * 16; wave = wave_; stg = 0; begin_stage(); }
@@ -61,7 +64,10 @@ struct BfStream {
 
 struct BfPipe { f32x4 fl[8]; DwSplit b; };     // carried between k-steps: the lo-level fragments and the split B operand of the NEXT k-step
 
-AF_DEV f32x4 bf_frag(const char* lane_base, int sl, int T, int lvl) { return *(const f32x4*)(lane_base + ((sl * 8 + T) * 3 + lvl) * 1024); }
+AF_DEV f32x4 bf_frag(const char* lane_base, int sl, int T, int lvl) {
+  if constexpr (AF_ABL & 8) return f32x4{(float)sl, (float)T, (float)lvl, 1.f};
+  return *(const f32x4*)(lane_base + ((sl * 8 + T) * 3 + lvl) * 1024);
+}
 AF_DEV f32x16 bf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../all-in-one-deflicker_amd/csrc/mlp.hip"
 #include "../all-in-one-deflicker_amd/csrc/mlp16.hip"
+#include "../all-in-one-deflicker_amd/csrc/mlpbf.hip"
 
 // Ceiling probe: a pure v_mfma_f32_32x32x2_f32 stream in the geometry of the chains — 256 threads,
 // one wave per SIMD (launch_bounds(256,1) + 128 KB of dynamic LDS so no second workgroup co-resides), 8 independent
@@ -44,9 +45,9 @@ __global__ __launch_bounds__(256, 1) void k_mfma_ceiling(float* out, int iters, 
 int main(int argc, char** argv) {
   const int NT = argc > 1 ? atoi(argv[1]) : 2813;
   const int reps = 20;
-  af_mlp_init(); af_mlp16_init();
+  af_mlp_init(); af_mlp16_init(); af_mlp_bf_init();
   // mapping1 image: forward 8K + 16 x 64K + 4K, backward 8K + 16 x 64K; every stage copies 64 KB -> pad
-  const size_t img_bytes = 8192 + 16 * 65536 + 4096 + 2 * 65536;
+  const size_t img_bytes = 8192 + 32 * 49152 + 4096 + 4 * 65536;     // covers the fp32 images and the bf16 stream of mapping1
   float *img, *bias, *in, *out, *acts, *dz, *dzl; uint32_t* masks;
   CK(hipMalloc(&img, img_bytes)); CK(hipMalloc(&bias, 8 * 256 * 4)); CK(hipMemset(bias, 0, 8 * 256 * 4));
   CK(hipMalloc(&in, (size_t)NT * 32 * 16)); CK(hipMemset(in, 0, (size_t)NT * 32 * 16));
@@ -76,13 +77,15 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  const char* names[4] = {"fwd_map32", "bwd_map32", "fwd_map16", "bwd_map16"};
-  for (int which = 0; which < 4; ++which) {
+  const char* names[6] = {"fwd_map32", "bwd_map32", "fwd_map16", "bwd_map16", "fwd_map32_bf16x6", "bwd_map32_bf16x6"};
+  for (int which = 0; which < 6; ++which) {
     auto go = [&]() {
       if (which == 0) { MultiFwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = fa; af_launch_fwd_multi(&m, 1, 0); }
       else if (which == 1) { MultiBwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = ba; af_launch_bwd_multi(&m, 0); }
       else if (which == 2) af_launch_fwd16(AF_NET_MAP1, &fa, 0);
-      else af_launch_bwd16(AF_NET_MAP1, &ba, 0);
+      else if (which == 3) af_launch_bwd16(AF_NET_MAP1, &ba, 0);
+      else if (which == 4) { MultiFwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = fa; af_launch_fwd_multi_bf(&m, 1, 0); }
+      else { MultiBwd m{}; m.n = 1; m.net[0] = AF_NET_MAP1; m.a[0] = ba; af_launch_bwd_multi_bf(&m, 0); }
     };
     for (int r = 0; r < 3; ++r) go();
     CK(hipDeviceSynchronize());
