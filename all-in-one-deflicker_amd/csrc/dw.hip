@@ -247,28 +247,14 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     dw_wait_vm<(DW_STAGES - 3) * NI>();                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
     dw_barrier();                                        // ... for every wave; every wave holds what it needs of stage s-1
     read_a(cur ^ 1, nslot);
-    if constexpr (!(DW_ABL & (16 | 32))) {
 #pragma unroll
-      for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);    // into the slot stage s-1 left
-    }
+    for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);      // into the slot stage s-1 left
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int y = 0; y < TIW; ++y) {
       DwSplit sbn = sb;
       if (y + 1 < TIW) sbn = dw_split8(rb[y + 1][0], rb[y + 1][1]);
       read_b(y, nslot);                                  // column y of stage s was split one region ago: its registers take stage s+1
-      if constexpr (DW_ABL & 32) {       // evenly spread: every wave issues NI / TIW pieces per column
-#pragma unroll
-        for (int k = y * ((NI + TIW - 1) / TIW); k < (y + 1) * ((NI + TIW - 1) / TIW) && k < NI; ++k) issue(s + DW_STAGES - 1, k);
-      }
-      if constexpr (DW_ABL & 16) {
-        // staggered DMA issue: wave w pushes its share of stage s+3 during column w only, so at any time one wave of the
-        // workgroup sits in the (blocking, when HBM-bound) VMEM issue while the other three keep their matrix pipes busy
-        if ((wave % TIW) == y) {
-#pragma unroll
-          for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);
-        }
-      }
       if constexpr (!(DW_ABL & 2)) {
 #pragma unroll
         for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.l, acc[x][y]);
