@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
-    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_set_dw_mode", "af_set_mlp_mode",
+    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
 ]
 
 
@@ -168,6 +168,7 @@ def load_library(path=None):
         "af_resize_bilinear": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i64, C.c_double, C.c_double, i32]),
         "af_flow_consistency": (i32, [i32, vp, vp, i32, i32, vp, i64, i64, C.c_float, i32]),
         "af_debug_dw_clocks": (i32, [vp, i32, vp, i32]),
+        "af_debug_dw_schedule": (i32, [vp, i32, vp, i32]),
         "af_set_dw_mode": (i32, [vp, i32]),
         "af_set_mlp_mode": (i32, [vp, i32]),
     }
@@ -411,6 +412,15 @@ class AtlasFit:
         if n < 0:
             self._chk(n)
         return out[:n]
+
+    def dw_schedule(self, which):
+        """(#workgroups, 16, 4) int32 segments {shape, t0, t1, job} of k_dw's static schedule `which` (0: 9 segments, 1: 7)."""
+        n = self.lib.af_debug_dw_schedule(self.h, int(which), None, 0)
+        if n < 0:
+            self._chk(n)
+        out = np.zeros((n, 16, 4), np.int32)
+        self.lib.af_debug_dw_schedule(self.h, int(which), _ptr(out), n)
+        return out
 
     def set_dw_mode(self, mode):
         """k_dw arithmetic: 1 = bf16x6 split operands on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check)."""

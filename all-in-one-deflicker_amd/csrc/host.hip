@@ -291,12 +291,14 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
     }
   }
   const int nj = (int)sc.jobs.size();
-  // Cost model in units of one 32x32 MFMA tile x 32 rows: MFMA tiles of the shape + a per-row-tile overhead (barrier,
-  // DMA issue, fragment reads), fitted on MI355X by sweeping both constants (tools/dwsweep.sh: 50 / 30 run k_dw 2.5 %
-  // faster than 20 / 20; the kernel time is flat within +-10 of either and climbs steeply outside).
-  const double ovh = getenv("AF_DW_OVH") ? atof(getenv("AF_DW_OVH")) : 50.0, ovh_s = getenv("AF_DW_OVH_S") ? atof(getenv("AF_DW_OVH_S")) : 30.0;
-  const double seg_cost = getenv("AF_DW_SEG") ? atof(getenv("AF_DW_SEG")) : 60.0;
-  auto tile_cost = [&](int j) { int To, Ti; return (double)shape_tiles(sc.jobs[j].shape, To, Ti) + (sc.jobs[j].shape == DW_8x8 ? ovh : ovh_s); };
+  // Cost of one 32-row tile of each job shape, in units of 1/306 of an 8x8 tile — measured per-workgroup busy times of a launch
+  // (s_memrealtime) against the segment lists, tools/dw_fit.py / tools/dw_dump.py.  Only the 8x8 jobs are matrix-pipe work; the
+  // narrow shapes (layer 0, skip columns, output layer) are bound by the latency of their 36-40 KB operand tiles, so they do not
+  // get cheaper when the 8x8 tiles move to the bf16 matrix pipe:
+  //   fp32 MFMA k_dw:  8x8 7.9 us/tile, 8x2 2.4, 8x1 1.6, 1x8 1.6, 1x2 1.2      bf16x6 k_dw_bf:  8x8 5.47, 8x2 2.0, 8x1 1.44, 1x8 1.44, 1x2 0.9
+  static const double kTileCost[2][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 126.0, 91.0, 91.0, 56.0}};
+  const double seg_cost = 60.0;
+  auto tile_cost = [&](int j) { return kTileCost[h->dw_mode ? 1 : 0][sc.jobs[j].shape]; };
   double work = 0;
   for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
   int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (4.0 * 276.0)));     // at least ~4 full-size row tiles per workgroup
@@ -1098,6 +1100,21 @@ int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
   if (out && h->dw_clock) HCHK(hipMemcpy(out, h->dw_clock, (size_t)std::min(cap_wg, h->ncu) * 16, hipMemcpyDeviceToHost));
   if (!enable && h->dw_clock) { (void)hipFree(h->dw_clock); h->dw_clock = nullptr; }
   return h->ncu;
+}
+
+int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg) {
+  // out [min(cap_wg, nwg)][DW_MAXSEG][4] = {job shape (DW_* enum), first row tile, one past the last, job index}, shape -1 = end of list
+  if (!h || which < 0 || which > 3) return AF_EINVAL;
+  const Sched& sc = h->sched[which];
+  if (out) {
+    for (int w = 0; w < std::min(cap_wg, sc.nwg); ++w)
+      for (int k = 0; k < DW_MAXSEG; ++k) {
+        const DwSeg& sg = sc.segs[(size_t)w * DW_MAXSEG + k];
+        int32_t* o = out + ((size_t)w * DW_MAXSEG + k) * 4;
+        o[0] = sg.job < 0 ? -1 : sc.jobs[sg.job].shape; o[1] = sg.t0; o[2] = sg.t1; o[3] = sg.job;
+      }
+  }
+  return sc.nwg;
 }
 
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out) {

@@ -20,11 +20,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA peak (2.5 PF; 2495 TF measured)
+BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # an fp32-faithful product = six bf16 partial products (bfsplit.h): 416.7 TF of fp32-equivalent work
 HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured for a streaming copy)
+# algorithmic HBM bytes of k_dw per 32-row tile of each net (every operand tile [features][32 rows] read once):
+# mapping1 4x64 + 36 + 36 KB, atlas 6x64 + 40 + 40 + 40 + 36 + 12, mapping2 2x64 + 36 + 36, alpha 6x64 + 40 + 36
+DW_TILE_BYTES = {"map1": 328 * 1024, "atlas": 512 * 1024, "map2": 200 * 1024, "alpha": 460 * 1024}
 METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs ref"     # BASELINE.json "metric"
 # launch classes of af_get_timing -> kernel names as rocprofv3 prints them
-KERNEL_OF_CLASS = {"fwd_1": "k_mlp_fwd_multi<true>", "fwd_2": "k_mlp_fwd_multi<true>", "bwd_1": "k_mlp_bwd_multi", "bwd_2": "k_mlp_bwd_multi",
-                   "dw": "k_dw_bf", "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
+MLP_BF = not os.environ.get("AF_MLP_FP32")      # default: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip)
+DW_BF = not os.environ.get("AF_DW_FP32")
+_FWD = "k_mlp_fwd_multi_bf<true>" if MLP_BF else "k_mlp_fwd_multi<true>"
+_BWD = "k_mlp_bwd_multi_bf" if MLP_BF else "k_mlp_bwd_multi"
+KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "dw": "k_dw_bf" if DW_BF else "k_dw",
+                   "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
 
 
 def synth_video_device(resx, resy, nframes, seed, device):
@@ -240,9 +249,7 @@ def main():
     by_name = {}
     for c in classes:
         by_name.setdefault(KERNEL_OF_CLASS[c], []).append(c)
-    if os.environ.get("AF_DW_FP32"):
-        by_name["k_dw"] = by_name.pop("k_dw_bf")
-    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else ("k_dw" if "k_dw" in by_name else "k_dw_bf")
+    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["dw"]
     dom_classes = by_name[dom]
     af.set_timing(sum(1 << classes.index(c) for c in dom_classes))   # events only around the dominant kernel's launches
 
@@ -299,13 +306,32 @@ def main():
     flops_launch = (sum(tk[c][2] for c in dom_classes) - (masked_dw_flops if is_dw else masked_mlp)) / n_launch
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
+    # algorithmic HBM bytes of k_dw per step: every operand tile of every layer read once, rows the reference does not evaluate excluded
+    rows_k = [af.step_work(first + k)[0] for k in range(K)]             # rows per net (NET_* order: map1, atlas, map2, alpha)
+    inv_per_step = inv / K
+    def dw_bytes(rows4):
+        r = {"map1": rows4[0] - inv_per_step, "atlas": rows4[1], "map2": (rows4[2] - inv_per_step) if args.two_layer else 0, "alpha": (rows4[3] - inv_per_step) if args.two_layer else 0}
+        return sum(DW_TILE_BYTES[n] * max(r[n], 0) / 32.0 for n in r)
+    dw_alg_bytes = sum(dw_bytes(r) for r in rows_k) / K
+    mfma_peak = BF16X6_PEAK_TFLOPS if (MLP_BF and not is_dw) or (DW_BF and is_dw) else FP32_MFMA_PEAK_TFLOPS
+    if is_dw and DW_BF:      # six bf16 products per fp32 product leave this kernel HBM-bound: the roofline is bytes, not flops
+        roof = {"bound": "hbm", "achieved": dw_alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": dw_alg_bytes}
+    else:
+        roof = {"bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["peak_definition"] = ("HBM3E 8 TB/s" if roof["bound"] == "hbm" else
+                               ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32-faithful product" if mfma_peak != FP32_MFMA_PEAK_TFLOPS else "FP32 MFMA peak"))
     # every hot kernel by name (warm-up pass, all launch classes timed): ms per step, TFLOP/s, fraction of the FP32-MFMA peak
     by_kernel = {}
     for kname, cls in by_name.items():
         ms = sum(tw[c][0] for c in cls); fl = sum(tw[c][2] for c in cls); nl = sum(tw[c][1] for c in cls)
         if ms > 0 and W > 0:
             by_kernel[kname] = {"ms_per_step": ms / W, "launches_per_step": nl / W, "tflops": (fl / ms / 1e9) if fl > 0 else None,
-                                "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None}
+                                "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None,
+                                "frac_of_bf16x6_peak": (fl / ms / 1e9 / BF16X6_PEAK_TFLOPS) if fl > 0 else None}
+            if "dw" in cls:
+                by_kernel[kname]["algorithmic_hbm_gbs"] = dw_alg_bytes / (ms / nl * 1e-3) / 1e9
+                by_kernel[kname]["frac_of_hbm_peak"] = by_kernel[kname]["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of
     # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
@@ -328,7 +354,8 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "sampled points/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16x6: operands split into 3 bf16, 6 partial products, fp32 accumulate)" if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
                                    "timed iterations %d..%d (global-rigidity rows while i <= 5000); %s"
                                    % (4 if args.two_layer else 1, " (fg/bg dual atlas + alpha MLP)" if args.two_layer else "",
@@ -337,8 +364,8 @@ def main():
                        "videos_per_gpu": V,
                        "samples_batch": N, "frames": args.frames, "resx": args.resx, "resy": args.resy},
             "pretrain_ms_per_step": pre_ms,
-            "roofline": {"bound": "mfma", "kernel": dom, "kernel_launch_classes": dom_classes, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+            "roofline": {**roof, "kernel": dom, "kernel_launch_classes": dom_classes, "achieved_tflops": achieved,
+                         "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                          "kernel_ms": dom_ms, "flops_per_launch": flops_launch, "launches_per_step": n_launch / K,
                          "by_kernel": by_kernel,
                          "valid_flow_fraction": float(nv.sum() / (2.0 * N * K)),

@@ -131,6 +131,10 @@ int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[
 /* Balance diagnostics of k_dw: enable != 0 makes every later k_dw launch record s_memrealtime (100 MHz) at the start and
  * end of each workgroup; out (nullable) receives [min(cap_wg, #CUs)][2] values of the most recent launch.  Returns #CUs. */
 int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
+/* The static split-K schedule of k_dw: which = 0 (9 row segments), 1 (7), 2 / 3 (pre-train of mapping1 / mapping2).
+ * out (nullable) [min(cap_wg, #workgroups)][16][4] int32 = {job shape 0..4 (8x8, 8x2, 8x1, 1x8, 1x2; -1 ends a list), first row tile,
+ * one past the last, job index}.  Returns the number of workgroups.  Used by tools/dw_fit.py to fit the schedule's cost model. */
+int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg);
 /* Read back n 64-byte pixel records of the packed table: out [n][16] = rgb(3), d/dx rgb(3), d/dy rgb(3), fwd flow(2),
  * bwd flow(2), fwd mask, bwd mask, fg mask, for pixel-frame indices inds[n] (the k of get_tuples' column k). */
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);

@@ -4,7 +4,7 @@
 #   the SQ counters (separate passes: FETCH_SIZE takes 3 of the 4 TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # Usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*.txt
 set -u
-TAG=${1:-r1c}
+TAG=${1:-r2}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
