@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const DwSeg* segs = a.segs + (size_t)blockIdx.x * DW_MAXSEG;
+#ifdef DW_CLK      // tools/dwbench.hip: core clock ticks instead of the 100 MHz counter
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+#else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int s = 0; s < DW_MAXSEG; ++s) {
     const DwSeg sg = segs[s];
     if (sg.job < 0) break;
@@ -334,7 +338,11 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
       default: break;
     }
   }
+#ifdef DW_CLK
+  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+#else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {

@@ -429,9 +429,17 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifdef AF_CLK      // tools/ablate.hip: core clock ticks (s_memtime) each workgroup spends, to read the shader clock under this load
+__device__ unsigned long long* g_af_clk;
+#define AF_CLK_MARK(i) if (threadIdx.x == 0 && g_af_clk) g_af_clk[blockIdx.x * 2 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define AF_CLK_MARK(i)
+#endif
+
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  AF_CLK_MARK(0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -441,10 +449,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
     case AF_NET_ATLAS: mlp_fwd_body_bf<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
     default:           mlp_fwd_body_bf<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
   }
+  AF_CLK_MARK(1);
 }
 
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  AF_CLK_MARK(0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -454,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
     case AF_NET_ATLAS: mlp_bwd_body_bf<NsAtlas>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body_bf<NsAlpha>(m.a[s], wg - base, smem); break;
   }
+  AF_CLK_MARK(1);
 }
 
 extern "C" int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s) {

@@ -95,6 +95,18 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double fl = (double)NT * 32 * ((which & 1) == 0 ? 526848.0 : 525312.0);
     printf("ABL=%d %s NT=%d: %.4f ms  %.1f TF (%.1f%% of 157.3)\n", AF_ABL, names[which], NT, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+#ifdef AF_CLK
+    if (which >= 4) {
+      const int nwg = (NT + 3) / 4;
+      unsigned long long* clk; CK(hipMalloc(&clk, (size_t)nwg * 16)); CK(hipMemset(clk, 0, (size_t)nwg * 16));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_af_clk), &clk, sizeof clk));
+      go(); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> hc((size_t)nwg * 2); CK(hipMemcpy(hc.data(), clk, (size_t)nwg * 16, hipMemcpyDeviceToHost));
+      double tk = 0; for (int w = 0; w < nwg; ++w) tk += (double)(hc[2 * w + 1] - hc[2 * w]); tk /= nwg;
+      unsigned long long* none = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_af_clk), &none, sizeof none));
+      printf("  mean core ticks per workgroup %.0f (MFMA issue alone: %d); ticks / launch time = %.0f MHz\n", tk, 4 * 16 * 48 * 32 + 2048, tk / (ms * 1000));
+    }
+#endif
   }
   return 0;
 }

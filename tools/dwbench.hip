@@ -8,7 +8,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main(int argc, char** argv) {
   const int per = argc > 1 ? atoi(argv[1]) : 66;       // row tiles per workgroup
-  const int nwg = 256, NT = per * nwg, reps = 10;
+  const int nwg = 256, NT = per * nwg, reps = argc > 3 ? atoi(argv[3]) : 10;
+  const int cached = argc > 2 ? atoi(argv[2]) : 0;      // 1: every tile index maps to tile 0 (operands L2-resident): the kernel without HBM
   af_dw_init();
   float *A, *B, *partial;
   CK(hipMalloc(&A, (size_t)NT * AF_TILE_F * 4)); CK(hipMalloc(&B, (size_t)NT * AF_TILE_F * 4));
@@ -18,7 +19,7 @@ int main(int argc, char** argv) {
     const size_t n = std::min(h.size(), (size_t)NT * AF_TILE_F - off);
     CK(hipMemcpy(A + off, h.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B + off, h.data(), n * 4, hipMemcpyHostToDevice));
   }
-  DwJob j{}; j.A = A; j.B = B; j.a_stride = AF_TILE_F; j.b_stride = AF_TILE_F; j.shape = DW_8x8; j.part_off = 0; j.part_blk = 65536 + 256;
+  DwJob j{}; j.A = A; j.B = B; j.a_stride = cached ? 0 : AF_TILE_F; j.b_stride = cached ? 0 : AF_TILE_F; j.shape = DW_8x8; j.part_off = 0; j.part_blk = 65536 + 256;
   std::vector<DwSeg> segs((size_t)nwg * DW_MAXSEG, DwSeg{-1, 0, 0, 0});
   for (int w = 0; w < nwg; ++w) segs[(size_t)w * DW_MAXSEG] = DwSeg{0, w * per, (w + 1) * per, w};
   DwJob* dj; DwSeg* ds; CK(hipMalloc(&dj, sizeof j)); CK(hipMalloc(&ds, segs.size() * sizeof(DwSeg)));
@@ -33,7 +34,17 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double fl = (double)NT * 32 * 2.0 * 256 * 256, by = (double)NT * 2 * AF_TILE_F * 4;
-    printf("DW_ABL=%d mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, mode, mode ? "bf16x6" : "fp32 MFMA", per, ms, fl / ms / 1e9, by / ms / 1e9);
+#ifdef DW_CLK     // core clock ticks each workgroup spent (s_memtime): ticks / event time = the shader clock under this load
+    if (mode == 1) {
+      unsigned long long* clk; CK(hipMalloc(&clk, nwg * 16));
+      DwArgs ac = a; ac.wg_clock = clk;
+      af_launch_dw(&ac, nwg, mode, 0); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> hc(nwg * 2); CK(hipMemcpy(hc.data(), clk, nwg * 16, hipMemcpyDeviceToHost));
+      double tk = 0; for (int w = 0; w < nwg; ++w) tk += (double)(hc[2 * w + 1] - hc[2 * w]); tk /= nwg;
+      printf("mean ticks per workgroup %.0f = %.0f per stage; over the launch time %.0f MHz\n", tk, tk / (2 * per), tk / (ms * 1000));
+    }
+#endif
+    printf("DW_ABL=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, cached ? " L2-resident" : "", mode, mode ? "bf16x6" : "fp32 MFMA", per, ms, fl / ms / 1e9, by / ms / 1e9);
   }
   return 0;
 }
