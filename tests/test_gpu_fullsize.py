@@ -259,6 +259,26 @@ def test_batch_without_valid_flow_reports_nan_like_reference():
     af.close()
 
 
+def test_nan_weight_is_reported_not_healed():
+    """torch's relu propagates NaN; v_max_f32(0, NaN) = 0 would let a blown-up net heal silently.  k_adam flags every NaN
+    gradient on the device, so a poisoned run ends in AF_ENAN even when no loss record is requested (the CLI's mode)."""
+    import aiod_amd
+    import bench
+    from oracle import atlas_oracle as O
+    v = O.synthetic_video(40, 24, 4, seed=2)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(40, 24, 4, samples_batch=128))
+    af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
+    sds = bench.init_state_dicts(1)
+    sd = {k: t.clone() for k, t in sds[aiod_amd.NET_ATLAS].items()}
+    key = sorted(k for k in sd if k.endswith("weight"))[0]                   # a hidden layer: its NaN pre-activations are what v_max_f32 would drop
+    sd[key].view(-1)[0] = float("nan")
+    af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1]); af.load_state_dict(aiod_amd.NET_ATLAS, sd)
+    with pytest.raises(aiod_amd.AtlasFitError) as e:
+        af.train_steps(0, 2, None, seed=0, return_losses=False)
+    assert e.value.code == -4
+    af.close()
+
+
 # ---- BASELINE configs[2]: 200 frames (the reference's maximum_number_of_frames), table resident in HBM
 def _records_from_source(video, inds, resx, resy):
     """What the 64-B record of pixel-frame index k must hold, gathered by torch from the reference-layout tensors."""
