@@ -55,6 +55,8 @@ struct FwdArgs {
   int tile0;                  // first row tile of this launch
   int NT;                     // one past the last row tile of this launch
   int nt_stride;              // row tiles per layer plane of acts / masks (the whole batch)
+  const int* live_rows;       // null, or: rows [live_base + *live_rows, NT*32) do not exist this iteration (compacted flow matches,
+  int live_base;              // written by k_prep); workgroups wholly beyond the last live row tile return at once
 };
 
 struct BwdArgs {
@@ -72,6 +74,7 @@ struct BwdArgs {
   int tile0;
   int NT;
   int nt_stride;
+  const int* live_rows; int live_base;      // as in FwdArgs
 };
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip
@@ -84,7 +87,8 @@ struct DwJob {
   int shape;                          // DW_*
   uint32_t part_off;                  // float offset of slot 0 in the partial buffer
   uint32_t part_blk;                  // floats per slot
-  int pad;
+  int live_base;                      // with live_rows: row tiles beyond row live_base + *live_rows hold stale data and are
+  const int* live_rows;               // skipped (a segment wholly beyond them stores a zero block); null: every tile is live
 };
 struct DwSeg { int job, t0, t1, slot; };
 #define DW_MAXSEG 16

@@ -314,6 +314,19 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
   }
 }
 
+// Compacted batches (DwJob::live_rows, written by k_prep): row tiles behind the last live row hold what an earlier iteration
+// left there.  Clip the segment to the live tiles; a segment with nothing left stores the zero block k_adam expects in its slot.
+AF_DEV bool dw_clip(const DwJob& jb, DwSeg& sg, float* partial, int tid) {
+  if (!jb.live_rows) return true;
+  const int nt = (jb.live_base + *jb.live_rows + 31) >> 5;
+  if (sg.t1 > nt) sg.t1 = nt;
+  if (sg.t0 < sg.t1) return true;
+  float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (uint32_t i = (uint32_t)tid * 4u; i < jb.part_blk; i += 1024u) *(f32x4*)(blk + i) = z;
+  return false;
+}
+
 __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -326,9 +339,10 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int s = 0; s < DW_MAXSEG; ++s) {
-    const DwSeg sg = segs[s];
+    DwSeg sg = segs[s];
     if (sg.job < 0) break;
     const DwJob jb = a.jobs[sg.job];
+    if (!dw_clip(jb, sg, a.partial, tid)) continue;
     switch (jb.shape) {      // 8x8: each wave a 4x4 block of output tiles (8 operand tiles to read and split per stage, the minimum)
       case DW_8x8: dw_segment_bf<8, 8, 4, 4>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2); break;
       case DW_8x2: dw_segment_bf<8, 2, 2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
@@ -353,9 +367,10 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
   const DwSeg* segs = a.segs + (size_t)blockIdx.x * DW_MAXSEG;
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
   for (int s = 0; s < DW_MAXSEG; ++s) {
-    const DwSeg sg = segs[s];
+    DwSeg sg = segs[s];
     if (sg.job < 0) break;
     const DwJob jb = a.jobs[sg.job];
+    if (!dw_clip(jb, sg, a.partial, tid)) continue;
     switch (jb.shape) {
       case DW_8x8: dw_segment<8, 8, 2, 8>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
       case DW_8x2: dw_segment<8, 2, 2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;

@@ -11,6 +11,7 @@ struct PackArgs {
   const float* mask_fg;   // (resy, resx, F) or null
   float* table;           // [F*resy*resx][16]
   int resx, resy, F;
+  unsigned long long* nvalid;   // [2] += records with a valid forward / backward flow match (what the batch planner expects per sample)
 };
 
 // Input builder (load_input_data*, unwrap_utils.py:40-163): bilinear resize with cv2.resize's INTER_LINEAR geometry
@@ -46,12 +47,20 @@ struct PrepArgs {
   float* x0_tile2;
   float* coordsA;         // [5N pad][4]
   int d_global2;
+  // compaction of the flow-match rows (loss_utils.py:328-335 evaluates the mapping nets on the VALID matches only): the
+  // matches of the batch are ranked sample-major (fwd before bwd) by a decoupled look-back scan over the blocks of this
+  // launch and written behind the fixed segments, row flow_base + rank (alpha net: 3N + rank).
+  int* flow_rank;         // [N][2] rank of the sample's fwd / bwd match among the valid matches, -1 when invalid
+  unsigned long long* scan;   // [gridDim.x] (epoch << 32 | matches of the block)
+  uint32_t epoch;         // unique per launch: a stale entry of an earlier launch can never satisfy the look-back
+  int* live;              // [1] valid matches of the batch = live rows behind flow_base
 };
 
 struct LossArgs {
   const float* samples; const float* out_map; const float* out_atlas;
   float* dout_map; float* dout_atlas;
   const int* counts;
+  const int* flow_rank; const int* live;      // see PrepArgs: rows of the valid flow matches, and how many there are
   float* loss_part;       // [nblocks][AF_LOSS_W]: rgb, gradient, rigidity, global rigidity, flow fwd, flow bwd (sums)
   int N, nseg;
   float L, uv_scale; int d_local, d_global;
@@ -68,6 +77,7 @@ struct LossSegArgs {
   const float* out_m1; const float* out_m2; const float* out_alpha; const float* out_atlas;
   float* dout_m1; float* dout_m2; float* dout_alpha; float* dout_atlas;
   const int* counts; float* loss_part;
+  const int* flow_rank; const int* live;
   int N, nseg;
   float L, uv_scale; int d_local, d_global_fg, d_global_bg;
   float c_rgb, c_grad, c_rig, c_grig_fg, c_grig_bg, c_flow, c_boot, c_aflow, c_sparse;

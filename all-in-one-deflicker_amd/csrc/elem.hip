@@ -32,7 +32,13 @@ AF_DEV uint64_t af_rand_below(uint64_t seed, uint32_t iter, uint32_t n, uint32_t
 __global__ void k_pack_table(PackArgs a) {
   const size_t P2 = (size_t)a.resx * a.resy;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P2 * a.F) return;
+  const bool in_range = idx < P2 * a.F;
+  const unsigned long long vf = __ballot(in_range && a.mask_f[idx] != 0.f), vb = __ballot(in_range && a.mask_b[idx] != 0.f);   // mask layout (pix, f) == idx
+  if (a.nvalid && (threadIdx.x & 63) == 0) {
+    if (vf) atomicAdd(a.nvalid + 0, (unsigned long long)__popcll(vf));
+    if (vb) atomicAdd(a.nvalid + 1, (unsigned long long)__popcll(vb));
+  }
+  if (!in_range) return;
   const int f = (int)(idx % a.F);
   const size_t pix = idx / a.F;
   const int x = (int)(pix % a.resx), y = (int)(pix / a.resx);
@@ -136,8 +142,10 @@ __global__ void k_flow_consistency(ConsistencyArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Batch preparation (stage1_neural_atlas.py:159-171; loss_utils.py:137-151, 230-233, 326-351).
-// Row segments of the mapping batch: 0 centre, 1 (x,y+1), 2 (x+1,y), 3 (x,y-d), 4 (x-d,y), 5 fwd-flow match,
-// 6 bwd-flow match, 7 (x,y-D), 8 (x-D,y); segments 7,8 exist only while the global rigidity term is on.
+// Row segments of the mapping batch (N rows each): 0 centre, 1 (x,y+1), 2 (x+1,y), 3 (x,y-d), 4 (x-d,y) and, while the
+// global rigidity term is on, 5 (x,y-D), 6 (x-D,y); behind them (flow_base = 5N or 7N) the flow matches of the batch,
+// VALID ones only and compacted like the reference's torch.where (loss_utils.py:328-335): sample-major, a sample's
+// forward match in front of its backward match.  a.nseg = 7 / 9 is the segment count of the un-compacted maximum.
 AF_DEV void put_row_to(float* coords, float* x0_tile, size_t r, float x, float y, float t) {
   f32x4 v = {x, y, t, 0.f};
   *(f32x4*)(coords + r * 4) = v;
@@ -146,31 +154,39 @@ AF_DEV void put_row_to(float* coords, float* x0_tile, size_t r, float x, float y
     tl[0] = x; tl[32] = y; tl[64] = t;
   }
 }
-// a row shared by both mapping nets (and, for aseg >= 0, by the alpha net as its segment aseg)
-AF_DEV void put_row(const PrepArgs& a, int seg, int aseg, int n, float x, float y, float t) {
-  const size_t r = (size_t)seg * a.N + n;
+// a row shared by both mapping nets (and, for arow >= 0, by the alpha net as its row arow)
+AF_DEV void put_row_at(const PrepArgs& a, size_t r, long long arow, float x, float y, float t) {
   put_row_to(a.coords, a.x0_tile, r, x, y, t);
   if (a.coords2) {
     put_row_to(a.coords2, a.x0_tile2, r, x, y, t);
-    if (aseg >= 0) put_row_to(a.coordsA, nullptr, (size_t)aseg * a.N + n, x, y, t);
+    if (arow >= 0) put_row_to(a.coordsA, nullptr, (size_t)arow, x, y, t);
   }
 }
+AF_DEV void put_row(const PrepArgs& a, int seg, int aseg, int n, float x, float y, float t) {
+  put_row_at(a, (size_t)seg * a.N + n, aseg >= 0 ? (long long)aseg * a.N + n : -1, x, y, t);
+}
 
-__global__ void k_prep(PrepArgs a) {
+__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+  __shared__ int wsum[4];
+  __shared__ int red_i[4];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int vf = 0, vb = 0;
+  int x = 0, y = 0, f = 0;
+  float ffu = 0.f, ffv = 0.f, fbu = 0.f, fbv = 0.f;
+  const float hm = a.half_main, hg = a.half_grad, hf = a.half_frames;
   if (n < a.N) {
     const uint64_t P2 = (uint64_t)a.resx * a.resy;
     const uint64_t k = a.inds ? (uint64_t)a.inds[n] : af_rand_below(a.seed, a.iter, (uint32_t)n, 0u, P2 * a.F);
-    const int f = (int)(k / P2);
+    f = (int)(k / P2);
     const uint64_t rem = k - (uint64_t)f * P2;
-    const int y = (int)(rem / a.resx), x = (int)(rem - (uint64_t)y * a.resx);
+    y = (int)(rem / a.resx); x = (int)(rem - (uint64_t)y * a.resx);
     const f32x4* rp = (const f32x4*)(a.table + k * AF_REC_F);
     f32x4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
     f32x4* sp = (f32x4*)(a.samples + (size_t)n * AF_REC_F);
     sp[0] = r0; sp[1] = r1; sp[2] = r2; sp[3] = r3;
-    const float ffu = r2[1], ffv = r2[2], fbu = r2[3], fbv = r3[0], mf = r3[1], mb = r3[2];
-    const float hm = a.half_main, hg = a.half_grad, hf = a.half_frames;
+    ffu = r2[1]; ffv = r2[2]; fbu = r2[3]; fbv = r3[0];
+    const float mf = r3[1], mb = r3[2];
     const float xc = (float)x / hm - 1.f, yc = (float)y / hm - 1.f, tc = (float)f / hf - 1.f;
     put_row(a, 0, 0, n, xc, yc, tc);
     put_row(a, 1, 1, n, (float)x / hg - 1.f, (float)(y + 1) / hg - 1.f, tc);
@@ -178,23 +194,49 @@ __global__ void k_prep(PrepArgs a) {
     put_row(a, 3, -1, n, xc, (float)(y - a.d_local) / hm - 1.f, tc);
     put_row(a, 4, -1, n, (float)(x - a.d_local) / hm - 1.f, yc, tc);
     vf = mf != 0.f; vb = mb != 0.f;
-    if (vf) put_row(a, 5, 3, n, ((float)x + ffu) / hm - 1.f, ((float)y + ffv) / hm - 1.f, (float)(f + 1) / hf - 1.f);
-    else    put_row(a, 5, 3, n, xc, yc, tc);
-    if (vb) put_row(a, 6, 4, n, ((float)x + fbu) / hm - 1.f, ((float)y + fbv) / hm - 1.f, (float)(f - 1) / hf - 1.f);
-    else    put_row(a, 6, 4, n, xc, yc, tc);
     if (a.nseg > 7) {
-      put_row_to(a.coords, a.x0_tile, (size_t)7 * a.N + n, xc, (float)(y - a.d_global) / hm - 1.f, tc);
-      put_row_to(a.coords, a.x0_tile, (size_t)8 * a.N + n, (float)(x - a.d_global) / hm - 1.f, yc, tc);
+      put_row_to(a.coords, a.x0_tile, (size_t)5 * a.N + n, xc, (float)(y - a.d_global) / hm - 1.f, tc);
+      put_row_to(a.coords, a.x0_tile, (size_t)6 * a.N + n, (float)(x - a.d_global) / hm - 1.f, yc, tc);
       if (a.coords2) {
-        put_row_to(a.coords2, a.x0_tile2, (size_t)7 * a.N + n, xc, (float)(y - a.d_global2) / hm - 1.f, tc);
-        put_row_to(a.coords2, a.x0_tile2, (size_t)8 * a.N + n, (float)(x - a.d_global2) / hm - 1.f, yc, tc);
+        put_row_to(a.coords2, a.x0_tile2, (size_t)5 * a.N + n, xc, (float)(y - a.d_global2) / hm - 1.f, tc);
+        put_row_to(a.coords2, a.x0_tile2, (size_t)6 * a.N + n, (float)(x - a.d_global2) / hm - 1.f, yc, tc);
       }
     }
   }
+  // ---- rank of this sample's matches among the valid matches of the batch
   const unsigned long long bf = __ballot(vf), bb = __ballot(vb);
-  if ((threadIdx.x & 63) == 0) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int in_wave = __popcll(bf & lt) + __popcll(bb & lt);
+  if (lane == 0) {
+    wsum[wave] = __popcll(bf) + __popcll(bb);
     if (bf) atomicAdd(a.counts + 0, __popcll(bf));
     if (bb) atomicAdd(a.counts + 1, __popcll(bb));
+  }
+  __syncthreads();
+  int in_block = in_wave;
+  for (int w = 0; w < wave; ++w) in_block += wsum[w];
+  const int btot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(a.scan + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)btot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  int pre = 0;      // look back: every block in front of this one is resident or finished (the grid is far smaller than the chip)
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += blockDim.x) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(a.scan + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != a.epoch);
+    pre += (int)(uint32_t)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+  if (lane == 0) red_i[wave] = pre;
+  __syncthreads();
+  pre = (red_i[0] + red_i[1]) + (red_i[2] + red_i[3]);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *a.live = pre + btot;
+  if (n < a.N) {
+    const int rank_f = pre + in_block, rank_b = rank_f + vf;
+    const size_t base = (size_t)(a.nseg - 2) * a.N, abase = (size_t)3 * a.N;
+    a.flow_rank[2 * n] = vf ? rank_f : -1;
+    a.flow_rank[2 * n + 1] = vb ? rank_b : -1;
+    if (vf) put_row_at(a, base + rank_f, (long long)(abase + rank_f), ((float)x + ffu) / hm - 1.f, ((float)y + ffv) / hm - 1.f, (float)(f + 1) / hf - 1.f);
+    if (vb) put_row_at(a, base + rank_b, (long long)(abase + rank_b), ((float)x + fbu) / hm - 1.f, ((float)y + fbv) / hm - 1.f, (float)(f - 1) / hf - 1.f);
   }
 }
 
@@ -281,21 +323,22 @@ __global__ __launch_bounds__(256) void k_loss_single(LossArgs a) {
     }
     // ---- global rigidity
     if (a.nseg > 7) {
-      const f32x4 pym = *(const f32x4*)(a.out_map + (7 * N + n) * 4);
-      const f32x4 pxm = *(const f32x4*)(a.out_map + (8 * N + n) * 4);
+      const f32x4 pym = *(const f32x4*)(a.out_map + (5 * N + n) * 4);
+      const f32x4 pxm = *(const f32x4*)(a.out_map + (6 * N + n) * 4);
       const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale, (float)a.d_global, a.c_grig * invN);
       l_grig = r.loss; du += r.du; dv += r.dv;
-      put_d2(a.dout_map, 7 * N + n, r.du_ym, r.dv_ym);
-      put_d2(a.dout_map, 8 * N + n, r.du_xm, r.dv_xm);
+      put_d2(a.dout_map, 5 * N + n, r.du_ym, r.dv_ym);
+      put_d2(a.dout_map, 6 * N + n, r.du_xm, r.dv_xm);
     }
-    // ---- optical flow (fwd: seg 5, count[0]; bwd: seg 6, count[1]); alpha == 1 in the single path
+    // ---- optical flow (fwd: count[0]; bwd: count[1]; the compacted rows of the valid matches); alpha == 1 in the single path
     const float fscale = a.L / (2.f * a.uv_scale);
+    const size_t flow_base = (size_t)(a.nseg - 2) * N;
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
-      const bool valid = sp[dir ? REC_MB : REC_MF] != 0.f;
-      const size_t row = (size_t)(5 + dir) * N + n;
-      float gu = 0.f, gv = 0.f;
-      if (valid) {
+      const int rank = a.flow_rank[2 * n + dir];
+      if (rank >= 0) {
+        const size_t row = flow_base + rank;
+        float gu = 0.f, gv = 0.f;
         const f32x4 m = *(const f32x4*)(a.out_map + row * 4);
         const float eu = m[0] - uvc[0], ev = m[1] - uvc[1];
         const float nrm = sqrtf(eu * eu + ev * ev);
@@ -305,10 +348,15 @@ __global__ __launch_bounds__(256) void k_loss_single(LossArgs a) {
         const float w = nrm > 0.f ? a.c_flow * 0.5f * fscale / (nrm * cnt) : 0.f;
         gu = w * eu; gv = w * ev;
         du -= gu; dv -= gv;
+        put_d2(a.dout_map, row, gu, gv);
       }
-      put_d2(a.dout_map, row, gu, gv);
     }
     put_d2(a.dout_map, (size_t)n, du, dv);
+  }
+  // rows between the last valid match and the end of its row tile are evaluated by the chains: they carry no gradient
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const size_t live_rows = (size_t)(a.nseg - 2) * a.N + *a.live, r = live_rows + threadIdx.x;
+    if (r < ((live_rows + 31) & ~(size_t)31)) put_d2(a.dout_map, r, 0.f, 0.f);
   }
   float s[6] = {l_rgb, l_grad, l_rig, l_grig, l_ff, l_fb};
 #pragma unroll
@@ -394,14 +442,15 @@ __global__ __launch_bounds__(256) void k_loss_seg(LossSegArgs a) {
     const float cntf = (float)a.counts[0], cntb = (float)a.counts[1];
     const bool vf = sp[REC_MF] != 0.f, vb = sp[REC_MB] != 0.f;
     // ---- alpha flow, L1 (loss_utils.py:385-408)
+    const int rank_f = a.flow_rank[2 * n], rank_b = a.flow_rank[2 * n + 1];
     if (vf) {
-      const float d = al - alpha_of(a.out_alpha[(3 * N + n) * 4]);
+      const float d = al - alpha_of(a.out_alpha[(3 * N + rank_f) * 4]);
       ls[10] = fabsf(d);
       const float g = a.c_aflow * 0.5f * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / cntf;
       dA += g; dAf = -g;
     }
     if (vb) {
-      const float d = alpha_of(a.out_alpha[(4 * N + n) * 4]) - al;
+      const float d = alpha_of(a.out_alpha[(3 * N + rank_b) * 4]) - al;
       ls[11] = fabsf(d);
       const float g = a.c_aflow * 0.5f * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / cntb;
       dAb = g; dA -= g;
@@ -425,22 +474,22 @@ __global__ __launch_bounds__(256) void k_loss_seg(LossSegArgs a) {
         put_d2(dm, 4 * N + n, r.du_xm, r.dv_xm);
       }
       if (a.nseg > 7) {
-        const f32x4 pym = *(const f32x4*)(om + (7 * N + n) * 4);
-        const f32x4 pxm = *(const f32x4*)(om + (8 * N + n) * 4);
+        const f32x4 pym = *(const f32x4*)(om + (5 * N + n) * 4);
+        const f32x4 pxm = *(const f32x4*)(om + (6 * N + n) * 4);
         const Rig r = rigidity(uvc[0], uvc[1], pym[0], pym[1], pxm[0], pxm[1], a.L, a.uv_scale,
                                (float)(net ? a.d_global_bg : a.d_global_fg), (net ? a.c_grig_bg : a.c_grig_fg) * invN);
         ls[4 + net] = r.loss; du += r.du; dv += r.dv;
-        put_d2(dm, 7 * N + n, r.du_ym, r.dv_ym);
-        put_d2(dm, 8 * N + n, r.du_xm, r.dv_xm);
+        put_d2(dm, 5 * N + n, r.du_ym, r.dv_ym);
+        put_d2(dm, 6 * N + n, r.du_xm, r.dv_xm);
       }
       const float wrow = net ? 1.f - al : al;        // flow rows are weighted by alpha (fg) / 1-alpha (bg), :285-293
       const float wsign = net ? -1.f : 1.f;
 #pragma unroll
       for (int dir = 0; dir < 2; ++dir) {
         const bool valid = dir ? vb : vf;
-        const size_t row = (size_t)(5 + dir) * N + n;
-        float gu = 0.f, gv = 0.f;
         if (valid) {
+          const size_t row = (size_t)(a.nseg - 2) * N + (dir ? rank_b : rank_f);
+          float gu = 0.f, gv = 0.f;
           const f32x4 m = *(const f32x4*)(om + row * 4);
           const float eu = m[0] - uvc[0], ev = m[1] - uvc[1];
           const float nrm = sqrtf(eu * eu + ev * ev);
@@ -451,8 +500,8 @@ __global__ __launch_bounds__(256) void k_loss_seg(LossSegArgs a) {
           gu = w * eu; gv = w * ev;
           du -= gu; dv -= gv;
           dA += wsign * a.c_flow * 0.5f * l / cnt;
+          put_d2(dm, row, gu, gv);
         }
-        put_d2(dm, row, gu, gv);
       }
       put_d2(dm, (size_t)n, du, dv);
     }
@@ -460,8 +509,15 @@ __global__ __launch_bounds__(256) void k_loss_seg(LossSegArgs a) {
     { f32x4 v = {AF_DALPHA * dA, 0.f, 0.f, 0.f};  *(f32x4*)(a.dout_alpha + (size_t)n * 4) = v; }
     { f32x4 v = {AF_DALPHA * dAy, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (N + n) * 4) = v; }
     { f32x4 v = {AF_DALPHA * dAx, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (2 * N + n) * 4) = v; }
-    { f32x4 v = {AF_DALPHA * dAf, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (3 * N + n) * 4) = v; }
-    { f32x4 v = {AF_DALPHA * dAb, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (4 * N + n) * 4) = v; }
+    if (vf) { f32x4 v = {AF_DALPHA * dAf, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (3 * N + rank_f) * 4) = v; }
+    if (vb) { f32x4 v = {AF_DALPHA * dAb, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (3 * N + rank_b) * 4) = v; }
+  }
+  // rows between the last valid match and the end of its row tile are evaluated by the chains: they carry no gradient
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const size_t live = (size_t)*a.live;
+    const size_t rm = (size_t)(a.nseg - 2) * a.N + live, ra = (size_t)3 * a.N + live;
+    if (rm + threadIdx.x < ((rm + 31) & ~(size_t)31)) { put_d2(a.dout_m1, rm + threadIdx.x, 0.f, 0.f); put_d2(a.dout_m2, rm + threadIdx.x, 0.f, 0.f); }
+    if (ra + threadIdx.x < ((ra + 31) & ~(size_t)31)) { f32x4 v = {0.f, 0.f, 0.f, 0.f}; *(f32x4*)(a.dout_alpha + (ra + threadIdx.x) * 4) = v; }
   }
 #pragma unroll
   for (int i = 0; i < 14; ++i) ls[i] = block_sum(ls[i], red);

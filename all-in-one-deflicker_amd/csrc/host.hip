@@ -101,6 +101,10 @@ struct af_handle {
   int* counts = nullptr; int loss_nblk_cap = 0; size_t loss_log_cap = 0;
   int* nan_flag = nullptr;                    // sticky, set on the device by k_adam: a non-finite parameter, a NaN loss term or an empty flow-match set
   int cur_nseg = 0;
+  // compaction of the flow-match rows (k_prep): per-sample ranks, look-back scan slots, live match count, launch epoch
+  int* flow_rank = nullptr; unsigned long long* scan = nullptr; int* live = nullptr; uint32_t prep_epoch = 0;
+  unsigned long long* nvalid = nullptr; double p_valid[2] = {1.0, 1.0};     // share of the video's pixels with a valid fwd / bwd match
+  int plan_flow_rows = 0;                                                   // flow-match rows the launches and the dW schedule are balanced for
   // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
   Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
   unsigned long long* dw_clock = nullptr;     // af_debug_dw_clocks: per-workgroup start/end times of the last k_dw launch
@@ -241,18 +245,21 @@ int shape_tiles(int shape, int& To, int& Ti) {
   }
 }
 
-struct NetUse { NetDesc* n; int NT; };
+struct NetUse { NetDesc* n; int NT; int live_base = -1; int NT_plan = -1; };     // live_base >= 0: rows behind live_base + *h->live are dead (compacted flow matches);
+                                                                          // NT_plan: the row tiles expected to be live (the schedule is balanced for them, NT is the capacity)
 
 // Build the dW job list, the Adam job list and the cost-balanced split-K schedule for a set of nets.
 bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   sc.jobs.clear(); sc.ajobs.clear(); sc.segs.clear();
-  std::vector<int> job_nt;
+  std::vector<int> job_nt, job_cap;       // row tiles the cut is balanced for / the job's last segment reaches (>= job_nt with compaction)
+  int cur_live_base = -1, cur_cap = 0;
   auto add = [&](NetDesc& n, int NT, int l, int shape, const float* A, uint32_t as, const float* B, uint32_t bs,
                  int col0, int in_real, bool owns_bias) {
     int To, Ti; shape_tiles(shape, To, Ti);
     DwJob j{}; j.A = A; j.B = B; j.a_stride = as; j.b_stride = bs; j.shape = shape;
+    if (cur_live_base >= 0) { j.live_base = cur_live_base; j.live_rows = h->live; }
     j.part_blk = (uint32_t)(To * 32 * Ti * 32 + To * 32);
-    sc.jobs.push_back(j); job_nt.push_back(NT);
+    sc.jobs.push_back(j); job_nt.push_back(NT); job_cap.push_back(cur_cap);
     AdamJob a{};
     a.part_blk = j.part_blk; a.pld = Ti * 32; a.out_real = n.out_feat[l]; a.in_real = in_real; a.out_real_pad = To * 32;
     a.p_off = (uint32_t)(n.p_base + n.w_off[l] + col0); a.p_ld = n.in_feat[l]; a.col0 = col0;
@@ -274,8 +281,10 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
     sc.ajobs.push_back(a);
   };
   for (const NetUse& u : uses) {
-    NetDesc& n = *u.n; const int NT = u.NT;
-    const size_t ts = (size_t)NT * AF_TILE_F;
+    NetDesc& n = *u.n;
+    const int NT = u.NT_plan >= 0 ? std::min(u.NT_plan, u.NT) : u.NT;      // the tensors' layer planes are u.NT tiles apart whatever is live
+    cur_live_base = u.live_base; cur_cap = u.NT;
+    const size_t ts = (size_t)u.NT * AF_TILE_F;
     for (int l = 0; l < n.NL; ++l) {
       const bool last = l == n.NL - 1, sk = (n.skip >> l) & 1;
       if (l == 0) {
@@ -325,6 +334,7 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
       }
       wg[w].push_back({j, t, t + take, nslots[j]++});
       cum += seg_cost + tc * take; t += take;
+      if (t == job_nt[j]) wg[w].back().t1 = job_cap[j];     // more valid matches than planned: the job's last segment takes them (k_dw clips at the live tiles)
       if (w < nwg - 1 && cum >= bound - 0.5 * tc) ++w;
     }
   }
@@ -354,6 +364,30 @@ hipError_t upload_sched(Sched& sc) {
 }
 
 int tiles_of(int rows) { return (rows + 31) / 32; }
+
+// Flow-match rows a batch is planned for: the expectation of its valid matches (the share of valid pixels of the uploaded
+// video, the sampler is uniform) + 4 sigma of the binomial, never more than 2N.  Launch splits and the dW schedule are
+// balanced for it; capacity stays 2N, a batch with more valid matches is still computed completely (just less evenly).
+int planned_flow_rows(const af_handle* h) {
+  const double N = h->N, pf = h->p_valid[0], pb = h->p_valid[1];
+  const double e = N * (pf + pb), sd = sqrt(std::max(0.0, N * (pf * (1.0 - pf) + pb * (1.0 - pb))));
+  return (int)std::min(2.0 * N, ceil(e + 4.0 * sd) + 32.0);
+}
+
+// the two schedules of the loop (0: with the global-rigidity rows, 1: without)
+bool build_main_scheds(af_handle* h) {
+  NetDesc& M = h->nets[AF_NET_MAP1]; NetDesc& A = h->nets[AF_NET_ATLAS]; NetDesc& M2 = h->nets[AF_NET_MAP2]; NetDesc& AL = h->nets[AF_NET_ALPHA];
+  const int N = h->N; const bool seg = h->seg;
+  h->plan_flow_rows = planned_flow_rows(h);
+  for (int v = 0; v < 2; ++v) {
+    const int nseg = v == 0 ? 9 : 7, fb = (nseg - 2) * N;
+    std::vector<NetUse> uses = {{&M, tiles_of(nseg * N), fb, tiles_of(fb + h->plan_flow_rows)}};
+    if (seg) { uses.push_back({&M2, tiles_of(nseg * N), fb, tiles_of(fb + h->plan_flow_rows)}); uses.push_back({&AL, tiles_of(5 * N), 3 * N, tiles_of(3 * N + h->plan_flow_rows)}); }
+    uses.push_back({&A, tiles_of((seg ? 6 : 3) * N)});
+    if (!build_sched(h, h->sched[v], uses)) return false;
+  }
+  return true;
+}
 
 hipError_t alloc_net_buffers(NetDesc& n, int rows_cap, bool own_coords) {
   n.nt_cap = tiles_of(rows_cap);
@@ -477,6 +511,7 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   else             LCHK(af_launch_bwd_multi(&m, h->stream));
   return 0;
 }
+template <class Args> Args with_live(Args a, const af_handle* h, int live_base) { a.live_rows = h->live; a.live_base = live_base; return a; }
 FwdArgs tile_range(FwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
 BwdArgs tile_range(BwdArgs a, int t0, int t1) { a.tile0 = t0; a.NT = t1; return a; }
 
@@ -548,14 +583,16 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     p.half_main = (float)(L / 2.0); p.half_grad = (float)(c.resx / 2.0); p.half_frames = (float)(c.number_of_frames / 2.0);
     p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
     p.coords = M.coords; p.x0_tile = M.x0_tile; p.samples = h->samples; p.counts = h->counts;
+    p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
     LCHK(af_launch_prep(&p, h->stream));
   }
   // Launch 1: the whole rounds of the mapping batch (they hold the 3N rows the atlas reads).  Launch 2: the atlas
   // chain plus the mapping remainder — rigidity / flow rows nothing in this launch depends on — in the CUs the
   // atlas workgroups leave idle.  The backward pass mirrors it (the remainder needs no atlas gradient).
   int rc, T1, T2;
-  plan_mapping_split(h->ncu, NT_map, NT_atlas, 3 * N, T1, T2);
-  const FwdArgs fm = fwd_args(h, M, M.coords, M.out_buf, NT_map, true, h->mlp_mode != 0);
+  plan_mapping_split(h->ncu, std::min(NT_map, tiles_of((nseg - 2) * N + h->plan_flow_rows)), NT_atlas, 3 * N, T1, T2);
+  const int flow_base = (nseg - 2) * N;      // rows behind flow_base + (valid matches of this batch) do not exist: the launches are sized for the maximum
+  const FwdArgs fm = with_live(fwd_args(h, M, M.coords, M.out_buf, NT_map, true, h->mlp_mode != 0), h, flow_base);
   if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_MAP1, tile_range(fm, 0, T1), nseg * N}}, true)) != 0) return rc;
   if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_MAP1, tile_range(fm, T1, T2), nseg * N},
                                     {AF_NET_ATLAS, fwd_args(h, A, M.out_buf, A.out_buf, NT_atlas, true, h->mlp_mode != 0), 3 * N},
@@ -564,7 +601,7 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     Timer t(h, T_LOSS);
     LossArgs l{};
     l.samples = h->samples; l.out_map = M.out_buf; l.out_atlas = A.out_buf; l.dout_map = M.dout; l.dout_atlas = A.dout;
-    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
+    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg; l.flow_rank = h->flow_rank; l.live = h->live;
     l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount; l.d_global = c.global_rigidity_derivative_amount_fg;
     l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
     l.c_grig = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_flow = c.optical_flow_coeff;
@@ -573,7 +610,7 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
   h->adam_step += 1;
   {
     BwdArgs ba = bwd_args(h, A, NT_atlas, h->mlp_mode != 0); ba.din0 = M.dout; ba.nrows = 3 * N;
-    const BwdArgs bm = bwd_args(h, M, NT_map, h->mlp_mode != 0);
+    const BwdArgs bm = with_live(bwd_args(h, M, NT_map, h->mlp_mode != 0), h, flow_base);
     if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_MAP1, tile_range(bm, T1, T2), nseg * N}, {AF_NET_ATLAS, ba, 3 * N},
                                       {AF_NET_MAP1, tile_range(bm, T2, NT_map), nseg * N}})) != 0) return rc;
     if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_MAP1, tile_range(bm, 0, T1), nseg * N}})) != 0) return rc;
@@ -605,6 +642,7 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
     p.coords = M1.coords; p.x0_tile = M1.x0_tile; p.samples = h->samples; p.counts = h->counts;
     p.coords2 = M2.coords; p.x0_tile2 = M2.x0_tile; p.coordsA = AL.coords; p.d_global2 = c.global_rigidity_derivative_amount_bg;
+    p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
     LCHK(af_launch_prep(&p, h->stream));
   }
   // Launch 1: alpha, mapping1, mapping2 (longest chains first, so the launch drains on the short ones).
@@ -612,20 +650,21 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
   // (background), :229-232 — topped up to whole rounds of the chip with the last alpha row tiles.
   int rc;
   const int wg_atlas = (NT_atlas + 3) / 4, pad = (h->ncu - wg_atlas % h->ncu) % h->ncu;
-  const int T_al = std::max(0, NT_alpha - 4 * pad);                 // alpha tiles [T_al, NT_alpha) ride with the atlas
-  const FwdArgs fal = fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true, h->mlp_mode != 0);
+  const int T_al = std::max(0, std::min(NT_alpha, tiles_of(3 * N + h->plan_flow_rows)) - 4 * pad);     // alpha tiles [T_al, NT_alpha) ride with the atlas (the expected live ones fill its last round)
+  const int flow_base = (nseg - 2) * N;      // mapping rows behind flow_base + (valid matches), alpha rows behind 3N + (valid matches) do not exist
+  const FwdArgs fal = with_live(fwd_args(h, AL, AL.coords, AL.out_buf, NT_alpha, true, h->mlp_mode != 0), h, 3 * N);
   FwdArgs fat = fwd_args(h, A, M1.out_buf, A.out_buf, NT_atlas, true, h->mlp_mode != 0);
   fat.in1 = M2.out_buf; fat.split_row = 3 * N;
   if ((rc = launch_fwd(h, T_FWD_1, {{AF_NET_ALPHA, tile_range(fal, 0, T_al), 5 * N},
-                                    {AF_NET_MAP1, fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true, h->mlp_mode != 0), nseg * N},
-                                    {AF_NET_MAP2, fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true, h->mlp_mode != 0), nseg * N}}, true)) != 0) return rc;
+                                    {AF_NET_MAP1, with_live(fwd_args(h, M1, M1.coords, M1.out_buf, NT_map, true, h->mlp_mode != 0), h, flow_base), nseg * N},
+                                    {AF_NET_MAP2, with_live(fwd_args(h, M2, M2.coords, M2.out_buf, NT_map, true, h->mlp_mode != 0), h, flow_base), nseg * N}}, true)) != 0) return rc;
   if ((rc = launch_fwd(h, T_FWD_2, {{AF_NET_ATLAS, fat, 6 * N}, {AF_NET_ALPHA, tile_range(fal, T_al, NT_alpha), 5 * N}}, true)) != 0) return rc;
   {
     Timer t(h, T_LOSS);
     LossSegArgs l{};
     l.samples = h->samples; l.out_m1 = M1.out_buf; l.out_m2 = M2.out_buf; l.out_alpha = AL.out_buf; l.out_atlas = A.out_buf;
     l.dout_m1 = M1.dout; l.dout_m2 = M2.dout; l.dout_alpha = AL.dout; l.dout_atlas = A.dout;
-    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg;
+    l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg; l.flow_rank = h->flow_rank; l.live = h->live;
     l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount;
     l.d_global_fg = c.global_rigidity_derivative_amount_fg; l.d_global_bg = c.global_rigidity_derivative_amount_bg;
     l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
@@ -639,10 +678,10 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
   {   // the mapping chains need the atlas chain's input gradient (rows < 3N): atlas (+ alpha top-up) first
     BwdArgs ba = bwd_args(h, A, NT_atlas, h->mlp_mode != 0);
     ba.din0 = M1.dout; ba.din1 = M2.dout; ba.split_row = 3 * N; ba.nrows = 6 * N;
-    const BwdArgs bal = bwd_args(h, AL, NT_alpha, h->mlp_mode != 0);
+    const BwdArgs bal = with_live(bwd_args(h, AL, NT_alpha, h->mlp_mode != 0), h, 3 * N);
     if ((rc = launch_bwd(h, T_BWD_1, {{AF_NET_ATLAS, ba, 6 * N}, {AF_NET_ALPHA, tile_range(bal, T_al, NT_alpha), 5 * N}})) != 0) return rc;
-    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, bwd_args(h, M1, NT_map, h->mlp_mode != 0), nseg * N},
-                                      {AF_NET_MAP2, bwd_args(h, M2, NT_map, h->mlp_mode != 0), nseg * N}})) != 0) return rc;
+    if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, with_live(bwd_args(h, M1, NT_map, h->mlp_mode != 0), h, flow_base), nseg * N},
+                                      {AF_NET_MAP2, with_live(bwd_args(h, M2, NT_map, h->mlp_mode != 0), h, flow_base), nseg * N}})) != 0) return rc;
   }
   const double dwf = (double)nseg * N * (kFlopFwd[AF_NET_MAP1] + kFlopFwd[AF_NET_MAP2]) + 6.0 * N * kFlopFwd[AF_NET_ATLAS] + 5.0 * N * kFlopFwd[AF_NET_ALPHA];
   return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
@@ -778,15 +817,12 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(dalloc(&h->loss_part, (size_t)h->loss_nblk_cap * AF_LOSS_W)); CCHK(hipMemset(h->loss_part, 0, (size_t)h->loss_nblk_cap * AF_LOSS_W * 4));
   CCHK(dalloc(&h->counts, 2)); CCHK(hipMemset(h->counts, 0, 8));
   CCHK(dalloc(&h->nan_flag, 1)); CCHK(hipMemset(h->nan_flag, 0, 4));
+  CCHK(dalloc(&h->flow_rank, (size_t)2 * N)); CCHK(hipMemset(h->flow_rank, 0xff, (size_t)2 * N * 4));
+  CCHK(dalloc(&h->scan, (size_t)(N + 255) / 256)); CCHK(hipMemset(h->scan, 0, (size_t)((N + 255) / 256) * 8));
+  CCHK(dalloc(&h->live, 1)); CCHK(hipMemset(h->live, 0, 4));
+  CCHK(dalloc(&h->nvalid, 2));
   // schedules
-  bool ok = true;
-  for (int v = 0; v < 2 && ok; ++v) {
-    const int nseg = v == 0 ? 9 : 7;
-    std::vector<NetUse> uses = {{&M, tiles_of(nseg * N)}};
-    if (seg) { uses.push_back({&M2, tiles_of(nseg * N)}); uses.push_back({&AL, tiles_of(5 * N)}); }
-    uses.push_back({&A, tiles_of((seg ? 6 : 3) * N)});
-    ok = build_sched(h, h->sched[v], uses);
-  }
+  bool ok = build_main_scheds(h);
   ok = ok && build_sched(h, h->sched[2], {{&M, tiles_of(rows_pre)}});
   if (seg) ok = ok && build_sched(h, h->sched[3], {{&M2, tiles_of(rows_pre)}});
   if (!ok) { h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup"); return die(AF_EINVAL); }
@@ -810,7 +846,7 @@ void af_destroy(af_handle* h) {
   for (Sched& s : h->sched) { (void)hipFree(s.d_jobs); (void)hipFree(s.d_ajobs); (void)hipFree(s.d_segs); }
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
   (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table); (void)hipFree(h->img_sf); (void)hipFree(h->img_sb);
-  (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts); (void)hipFree(h->nan_flag);
+  (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts); (void)hipFree(h->nan_flag); (void)hipFree(h->flow_rank); (void)hipFree(h->scan); (void)hipFree(h->live); (void)hipFree(h->nvalid);
   (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
   (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -845,10 +881,28 @@ int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, co
     dev[i] = tmp[i];
   }
   if (rc == AF_OK) {
-    PackArgs a{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], h->table, h->cfg.resx, h->cfg.resy, h->cfg.number_of_frames};
-    int r = af_launch_pack(&a, h->stream);
-    hipError_t e = r ? (hipError_t)r : hipStreamSynchronize(h->stream);
+    PackArgs a{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], h->table, h->cfg.resx, h->cfg.resy, h->cfg.number_of_frames, h->nvalid};
+    hipError_t e = hipMemsetAsync(h->nvalid, 0, 16, h->stream);
+    int r = e == hipSuccess ? af_launch_pack(&a, h->stream) : (int)e;
+    e = r ? (hipError_t)r : hipStreamSynchronize(h->stream);
+    unsigned long long nv[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(nv, h->nvalid, 16, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = h->fail(AF_EHIP, "pack table", e);
+    else {
+      // re-balance launches and dW schedule for the share of valid flow matches of THIS video (the rows are compacted on the device)
+      h->p_valid[0] = (double)nv[0] / (double)P; h->p_valid[1] = (double)nv[1] / (double)P;
+      if (planned_flow_rows(h) != h->plan_flow_rows) {
+        if (!build_main_scheds(h)) rc = h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup");
+        for (int i = 0; i < 2 && rc == AF_OK; ++i) {
+          if ((e = upload_sched(h->sched[i])) != hipSuccess) rc = h->fail(AF_EHIP, "schedule upload", e);
+          if (rc == AF_OK && h->sched[i].partial_floats > h->partial_cap) {
+            (void)hipFree(h->partial); h->partial = nullptr;
+            if ((e = dalloc(&h->partial, h->sched[i].partial_floats)) != hipSuccess) rc = h->fail(AF_ENOMEM, "partial dW buffer", e);
+            else h->partial_cap = h->sched[i].partial_floats;
+          }
+        }
+      }
+    }
   }
   for (int i = 0; i < 6; ++i) if (tmp[i]) (void)hipFree(tmp[i]);
   if (rc == AF_OK) { h->have_video = true; std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0); }

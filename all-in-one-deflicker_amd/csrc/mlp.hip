@@ -21,8 +21,10 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
   int tile = a.tile0 + wg * 4 + wave;
-  const bool live = tile < a.NT;
-  if (!live) tile = a.NT - 1;
+  const int NT = live_tiles(a);
+  if (a.tile0 + wg * 4 >= NT) return;                  // a workgroup of rows that do not exist this iteration (uniform: before any barrier)
+  const bool live = tile < NT;
+  if (!live) tile = NT - 1;
   const int row = tile * 32 + j;
 
   using CB = ChunkBytes<NS>;
@@ -182,8 +184,10 @@ AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
   int tile = a.tile0 + wg * 4 + wave;
-  const bool live = tile < a.NT;
-  if (!live) tile = a.NT - 1;
+  const int NT = live_tiles(a);
+  if (a.tile0 + wg * 4 >= NT) return;                  // a workgroup of rows that do not exist this iteration (uniform: before any barrier)
+  const bool live = tile < NT;
+  if (!live) tile = NT - 1;
   const int row = tile * 32 + j;
 
   using CB = ChunkBytes<NS>;

@@ -71,6 +71,14 @@ AF_DEV float af_relu(float z) { float v; asm("v_max_f32 %0, 0, %1" : "=v"(v) : "
 // they replace (each VMEM instruction steals ~40 cycles of MFMA issue from the only wave of its SIMD).
 #define AF_BIAS_LDS (2 * AF_CHUNK_MAX)          // byte offset of the bias rows in dynamic LDS
 #define AF_LDS_BYTES (2 * AF_CHUNK_MAX + AF_MAX_LAYERS * AF_HID * 4)
+// Row tiles a launch really has: the static count, or — when the batch's flow-match rows are compacted on the device
+// (k_prep, elem.hip) — the tiles up to the last live row.
+template <class Args> AF_DEV int live_tiles(const Args& a) {
+  if (!a.live_rows) return a.NT;
+  const int nt = (a.live_base + *a.live_rows + 31) >> 5;
+  return nt < a.NT ? nt : a.NT;
+}
+
 template <int NL> AF_DEV void stage_bias(const float* bias, char* bias_lds, int tid) {
   float* dst = (float*)bias_lds;
 #pragma unroll

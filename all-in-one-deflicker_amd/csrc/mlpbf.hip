@@ -46,6 +46,7 @@ struct BfStream {
   AF_DEV void begin_stage() { p_dst = smem + (stg & 1) * AF_SLOT_BF + wave * 1024; p_it = 0; }
   AF_DEV void issue1() {
     const int k = p_it < NI ? p_it : NI - 1;
+    if constexpr ((AF_ABL & 64) != 0) { if (wave != 0) { ++p_it; return; } }       // timing probe: only wave 0 feeds the texture addresser
     if constexpr (!(AF_ABL & 2)) af_glds16(src + k * 4096, p_dst + k * 4096);
     ++p_it;
   }
@@ -172,8 +173,10 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
   int tile = a.tile0 + wg * 4 + wave;
-  const bool live = tile < a.NT;
-  if (!live) tile = a.NT - 1;
+  const int NT = live_tiles(a);
+  if (a.tile0 + wg * 4 >= NT) return;                  // a workgroup of rows that do not exist this iteration (uniform: before any barrier)
+  const bool live = tile < NT;
+  if (!live) tile = NT - 1;
   const int row = tile * 32 + j;
 
   using CB = ChunkBytesBf<NS>;
@@ -340,8 +343,10 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, h = lane >> 5;
   int tile = a.tile0 + wg * 4 + wave;
-  const bool live = tile < a.NT;
-  if (!live) tile = a.NT - 1;
+  const int NT = live_tiles(a);
+  if (a.tile0 + wg * 4 >= NT) return;                  // a workgroup of rows that do not exist this iteration (uniform: before any barrier)
+  const bool live = tile < NT;
+  if (!live) tile = NT - 1;
   const int row = tile * 32 + j;
 
   using CB = ChunkBytesBf<NS>;

@@ -227,3 +227,47 @@ def test_ragged_sizes_match_oracle(golden_seg, two_layer):
             gh, gr = h.last_grads(net), O.flat_grads(m)
             assert np.linalg.norm(gh - gr) < 2e-3 * np.linalg.norm(gr), (it, net)
     h.close()
+
+
+@pytest.mark.parametrize("two_layer", [False, True])
+@pytest.mark.parametrize("keep", [0.5, 0.04])
+def test_compacted_flow_rows_match_oracle(golden_seg, two_layer, keep):
+    """loss_utils.py:328-335: the flow terms evaluate the mapping (and alpha) nets on the VALID matches only.  k_prep compacts
+    them behind the fixed row segments (device-side scan), the chains / k_dw stop at the last live row tile: half of the matches
+    masked, and almost all of them (a handful of live rows, most launched workgroups dead), with and without the global rows."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    cfg = dict(golden_seg["config"]); cfg.update(samples_batch=700, stop_global_rigidity=5)
+    v = O.synthetic_seg_video(33, 26, 6, seed=5)
+    gm = torch.Generator().manual_seed(17)
+    v.optical_flows_mask = v.optical_flows_mask * (torch.rand(v.optical_flows_mask.shape, generator=gm) < keep).float()
+    v.optical_flows_reverse_mask = v.optical_flows_reverse_mask * (torch.rand(v.optical_flows_reverse_mask.shape, generator=gm) < keep * 0.8).float()
+    if two_layer:
+        models = O.build_seg_models(cfg, seed=3)
+        nets = _nets()
+        tr = O.SegAtlasTrainer(cfg, v, models=models)
+        names = O.SEG_TERMS
+    else:
+        models = O.build_single_atlas_models(cfg, seed=3)
+        nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS)
+        tr = O.SingleAtlasTrainer(cfg, v, mapping=models[0], atlas=models[1])
+        names = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+    h = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg, two_layer=two_layer))
+    h.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask,
+                   v.mask_frames if two_layer else None)
+    g = torch.Generator().manual_seed(4)
+    h.set_debug(True)
+    for it in (2, 9, 3):                               # with, without, and again with the global-rigidity rows (the row layout switches back)
+        inds = torch.randint(v.F * v.resx * v.resy, (700,), generator=g)
+        for net, m in zip(nets, models):               # same state on both sides before every comparison
+            h.load_state_dict(net, m.state_dict())
+        ref = tr.loss_and_grads(it, inds)
+        got = h.train_steps(it, 1, inds.numpy())[0]
+        nvalid = got[len(names):len(names) + 2]             # the two counters sit right behind the loss terms
+        assert 0 < nvalid[0] < 700 * keep * 2 + 10 and 0 < nvalid[1] < 700 * keep * 2 + 10, nvalid
+        assert np.allclose(got[:len(names)], [ref[k] for k in names], rtol=1e-3, atol=1e-6), (it, got, ref)
+        for net, m in zip(nets, models):
+            gh, gr = h.last_grads(net), O.flat_grads(m)
+            # un-pre-trained nets: torch-fp32's own atlas gradient is 3e-3 from an fp64 twin here (test_first_step_losses_and_gradients...)
+            assert np.linalg.norm(gh - gr) < 4e-3 * np.linalg.norm(gr), (it, net)
+    h.close()
