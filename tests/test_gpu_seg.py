@@ -271,3 +271,43 @@ def test_compacted_flow_rows_match_oracle(golden_seg, two_layer, keep):
             # un-pre-trained nets: torch-fp32's own atlas gradient is 3e-3 from an fp64 twin here (test_first_step_losses_and_gradients...)
             assert np.linalg.norm(gh - gr) < 4e-3 * np.linalg.norm(gr), (it, net)
     h.close()
+
+
+@pytest.mark.parametrize("two_layer", [False, True])
+def test_more_valid_matches_than_planned(golden_seg, two_layer):
+    """Launch split and dW schedule are balanced for the matches the video's share of valid pixels lets one expect (+4 sigma);
+    capacity stays 2N.  A batch drawn only from the valid half of a half-masked video has twice the planned matches: the job's
+    last dW segment and the trailing workgroups of the chains must take them all."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    cfg = dict(golden_seg["config"]); cfg.update(samples_batch=900, stop_global_rigidity=5)
+    v = O.synthetic_seg_video(40, 30, 6, seed=8)
+    half = torch.zeros(6); half[:3] = 1.0                                    # frames 0..2 keep their matches, frames 3..5 lose them
+    v.optical_flows_mask = v.optical_flows_mask * half.view(1, 1, -1, *([1] * (v.optical_flows_mask.dim() - 3)))
+    v.optical_flows_reverse_mask = v.optical_flows_reverse_mask * half.view(1, 1, -1, *([1] * (v.optical_flows_reverse_mask.dim() - 3)))
+    if two_layer:
+        models = O.build_seg_models(cfg, seed=3); nets = _nets()
+        tr = O.SegAtlasTrainer(cfg, v, models=models); names = O.SEG_TERMS
+    else:
+        models = O.build_single_atlas_models(cfg, seed=3); nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_ATLAS)
+        tr = O.SingleAtlasTrainer(cfg, v, mapping=models[0], atlas=models[1])
+        names = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+    h = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg, two_layer=two_layer))
+    h.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask,
+                   v.mask_frames if two_layer else None)
+    g = torch.Generator().manual_seed(4)
+    h.set_debug(True)
+    P2 = v.resx * v.resy
+    for it in (2, 9):
+        inds = torch.randint(P2 * 1, P2 * 2, (900,), generator=g)            # frame 1 only: almost every sample has both matches
+        for net, m in zip(nets, models):
+            h.load_state_dict(net, m.state_dict())
+        ref = tr.loss_and_grads(it, inds)
+        got = h.train_steps(it, 1, inds.numpy())[0]
+        nvalid = got[len(names):len(names) + 2]
+        assert nvalid[0] + nvalid[1] > 1.5 * 900, nvalid                     # planned: about 900 + 4 sigma
+        assert np.allclose(got[:len(names)], [ref[k] for k in names], rtol=1e-3, atol=1e-6), (it, got, ref)
+        for net, m in zip(nets, models):
+            gh, gr = h.last_grads(net), O.flat_grads(m)
+            assert np.linalg.norm(gh - gr) < 4e-3 * np.linalg.norm(gr), (it, net)
+    h.close()
