@@ -45,21 +45,23 @@ __global__ __launch_bounds__(256, 1) void k_mfma_ceiling(float* out, int iters, 
 int main(int argc, char** argv) {
   const int NT = argc > 1 ? atoi(argv[1]) : 2813;
   const int reps = 20;
+  const int only_net = argc > 3 ? atoi(argv[3]) : -1;     // ablate <NT> 0 <net>: the bf16x6 chains of that net alone (0 mapping1, 1 atlas, 2 mapping2, 3 alpha)
   af_mlp_init(); af_mlp16_init(); af_mlp_bf_init();
   // mapping1 image: forward 8K + 16 x 64K + 4K, backward 8K + 16 x 64K; every stage copies 64 KB -> pad
-  const size_t img_bytes = 8192 + 32 * 49152 + 4096 + 4 * 65536;     // covers the fp32 images and the bf16 stream of mapping1
+  const size_t img_bytes = (size_t)16 << 20;         // covers the fp32 images and the bf16 stream of mapping1
   float *img, *bias, *in, *out, *acts, *dz, *dzl; uint32_t* masks;
   CK(hipMalloc(&img, img_bytes)); CK(hipMalloc(&bias, 8 * 256 * 4)); CK(hipMemset(bias, 0, 8 * 256 * 4));
   CK(hipMalloc(&in, (size_t)NT * 32 * 16)); CK(hipMemset(in, 0, (size_t)NT * 32 * 16));
   CK(hipMalloc(&out, (size_t)NT * 32 * 16)); CK(hipMemset(out, 0, (size_t)NT * 32 * 16));
-  CK(hipMalloc(&acts, (size_t)5 * NT * 32768)); CK(hipMalloc(&dz, (size_t)5 * NT * 32768));
-  CK(hipMalloc(&dzl, (size_t)NT * 4096)); CK(hipMalloc(&masks, (size_t)5 * NT * 1024)); CK(hipMemset(masks, 0xff, (size_t)5 * NT * 1024));
+  CK(hipMalloc(&acts, (size_t)7 * NT * 32768)); CK(hipMalloc(&dz, (size_t)7 * NT * 32768));
+  CK(hipMalloc(&dzl, (size_t)NT * 4096)); CK(hipMalloc(&masks, (size_t)7 * NT * 1024)); CK(hipMemset(masks, 0xff, (size_t)7 * NT * 1024));
+  float* pe_tile; CK(hipMalloc(&pe_tile, (size_t)NT * 8192)); CK(hipMemset(pe_tile, 0, (size_t)NT * 8192));
   std::vector<float> w(img_bytes / 4); for (auto& x : w) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
   CK(hipMemcpy(img, w.data(), img_bytes, hipMemcpyHostToDevice));
   FwdArgs fa{}; fa.wimg = img; fa.bias = bias; fa.in = in; fa.in1 = nullptr; fa.out = out; fa.acts = acts; fa.masks = masks;
-  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT;
+  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.pe_tile = pe_tile;
   BwdArgs ba{}; ba.wimg = img; ba.out = out; ba.dout = in; ba.masks = masks; ba.dz = dz; ba.dz_last = dzl;
-  ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT;
+  ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT; ba.pe_tile = pe_tile;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   if (argc > 2 && atoi(argv[2]) == 1) {     // ablate <NT> 1: the pure-MFMA ceiling
     CK(hipFuncSetAttribute((const void*)k_mfma_ceiling, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -74,6 +76,24 @@ int main(int argc, char** argv) {
       const double fl = (double)wgs * 4 * iters * 32 * 4096.0;
       printf("mfma_ceiling wgs=%d: %.4f ms  %.1f TF (%.1f%% of 157.3; %.1f%% counting whole rounds of 256 CUs)\n", wgs, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100,
              (double)((wgs + 255) / 256 * 256) * 4 * iters * 32 * 4096.0 / ms / 1e9 / 157.3 * 100);
+    }
+    return 0;
+  }
+  if (only_net >= 0) {
+    std::vector<float> hin((size_t)NT * 32 * 4); for (auto& x : hin) x = rand() / (float)RAND_MAX * 2.f - 1.f;     // uv in [-1, 1] like the tanh outputs the PE nets read
+    CK(hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+    for (int dir = 0; dir < 2; ++dir) {
+      auto go = [&]() {
+        if (dir == 0) { MultiFwd m{}; m.n = 1; m.net[0] = only_net; m.a[0] = fa; af_launch_fwd_multi_bf(&m, 1, 0); }
+        else { MultiBwd m{}; m.n = 1; m.net[0] = only_net; m.a[0] = ba; af_launch_bwd_multi_bf(&m, 0); }
+      };
+      for (int r = 0; r < 3; ++r) go();
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) go();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      printf("net %d %s bf16x6 chain, NT=%d (%.2f rounds of 1024 SIMDs): %.1f us\n", only_net, dir ? "bwd" : "fwd", NT, NT / 1024.0, ms * 1000);
     }
     return 0;
   }
