@@ -6,7 +6,8 @@
 #include "af_dev.h"
 
 #ifndef AF_ABL
-#define AF_ABL 0   // bit0 no tile stores, bit1 no LDS-DMA, bit2 no barriers, bit3 no LDS fragment reads, bit4 no sched_barrier
+#define AF_ABL 0   // tools/ablate.hip timing probes: bit0 no tile stores, bit1 no LDS-DMA, bit2 no barriers, bit3 no LDS fragment reads, bit4 no
+                   // sched_barrier, bit5 no operand split, bit6 only wave 0 issues the LDS-DMA, bit8 atlas PE without sin / cos, bit9 with sincosf
 #endif
 
 struct NsMap1  { static constexpr int NL = 6, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };

@@ -197,7 +197,9 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
       for (int g = 0; g < 5; ++g) {
         const float b = h ? __builtin_ldexpf(3.14159265358979323846f, 2 * g + 1) : __builtin_ldexpf(3.14159265358979323846f, 2 * g);
         const float p0 = x0 * b, p1 = x1 * b;
-        pe[g * 4 + 0] = sinf(p0); pe[g * 4 + 1] = sinf(p1); pe[g * 4 + 2] = cosf(p0); pe[g * 4 + 3] = cosf(p1);
+        if constexpr ((AF_ABL & 256) != 0) { pe[g * 4 + 0] = p0; pe[g * 4 + 1] = p1; pe[g * 4 + 2] = -p0; pe[g * 4 + 3] = -p1; }      // timing probe: no sin / cos
+        else if constexpr ((AF_ABL & 512) != 0) { sincosf(p0, &pe[g * 4 + 0], &pe[g * 4 + 2]); sincosf(p1, &pe[g * 4 + 1], &pe[g * 4 + 3]); }
+        else { pe[g * 4 + 0] = sinf(p0); pe[g * 4 + 1] = sinf(p1); pe[g * 4 + 2] = cosf(p0); pe[g * 4 + 3] = cosf(p1); }
       }
     } else {   // AF_IN_PE3: lane half h owns k in {2h, 2h+1} (+ sin/cos triple of k = 4)
       const float x[3] = {v[0], v[1], v[2]};
