@@ -14,10 +14,11 @@ same draws from the seed alone (tests/test_gpu_c1.py) — the fixture only store
     tests/golden/c1_reference.npz   per seed: PSNR after the pre-train, final PSNR (mean + per frame), the six
                                     loss terms every 100 iterations, wall-clock of the CPU run (5 threads)
     tests/golden/c1_reference_rerun.npz
-                                    the same for seed 0 alone with 3 threads (`--seeds 0 --threads 3 --out ...`): the
-                                    reference against ITSELF.  Only the summation order inside its GEMMs changes, and
-                                    the final PSNR moves by 0.51 dB (25.013 -> 25.523), single frames by up to 2.5 dB:
-                                    this is the reproducibility floor tests/test_gpu_c1.py builds its tolerances on
+                                    the same three seeds with 3 threads (`--seeds k --threads 3 --out ...` per seed,
+                                    merged): the reference against ITSELF.  Only the summation order inside its GEMMs
+                                    changes, and the final PSNR moves by up to 0.51 dB on a seed (25.013 -> 25.523 on
+                                    seed 0; means over the seeds 25.525 vs 25.647 dB), single frames by up to 2.5 dB:
+                                    the reproducibility floor tests/test_gpu_c1.py builds its tolerances on
 
 Build container only (imports /root/reference read-only; ~17 min of CPU per seed):
 

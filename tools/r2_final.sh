@@ -10,7 +10,10 @@ timeout 900 bash tools/collect_profiles.sh r2 > $OUT/r2f_collect.log 2>&1
 timeout 400 python bench.py > $OUT/r2_bench.json 2> $OUT/r2_bench.err
 timeout 300 python bench.py --no-cpu-baseline --two-layer > $OUT/r2_bench_two_layer.json 2> $OUT/r2_bench_two_layer.err
 timeout 300 python bench.py --no-cpu-baseline --valid-fraction 0.7 > $OUT/r2_bench_valid07.json 2> $OUT/r2_bench_valid07.err
-for f in r2_bench r2_bench_two_layer r2_bench_valid07 r2_bench_unprofiled; do python - <<PY
+timeout 300 python bench.py --no-cpu-baseline --valid-fraction 0.5 > $OUT/r2_bench_valid05.json 2> $OUT/r2_bench_valid05.err
+timeout 300 python bench.py --no-cpu-baseline --two-layer --valid-fraction 0.7 > $OUT/r2_bench_two_layer_valid07.json 2> $OUT/r2_bench_two_layer_valid07.err
+timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 50 > $OUT/r2_bench_8000.json 2> $OUT/r2_bench_8000.err
+for f in r2_bench r2_bench_8000 r2_bench_two_layer r2_bench_valid07 r2_bench_valid05 r2_bench_two_layer_valid07 r2_bench_unprofiled; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1]); r=d["roofline"]
