@@ -11,7 +11,7 @@ struct PackArgs {
   const float* mask_fg;   // (resy, resx, F) or null
   float* table;           // [F*resy*resx][16]
   int resx, resy, F;
-  unsigned long long* nvalid;   // [2] += records with a valid forward / backward flow match (what the batch planner expects per sample)
+  unsigned long long* nvalid;   // [64][2] += records with a valid forward / backward flow match (64 spread counters; what the batch planner expects per sample)
 };
 
 // Input builder (load_input_data*, unwrap_utils.py:40-163): bilinear resize with cv2.resize's INTER_LINEAR geometry

@@ -34,9 +34,10 @@ __global__ void k_pack_table(PackArgs a) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = idx < P2 * a.F;
   const unsigned long long vf = __ballot(in_range && a.mask_f[idx] != 0.f), vb = __ballot(in_range && a.mask_b[idx] != 0.f);   // mask layout (pix, f) == idx
-  if (a.nvalid && (threadIdx.x & 63) == 0) {
-    if (vf) atomicAdd(a.nvalid + 0, (unsigned long long)__popcll(vf));
-    if (vb) atomicAdd(a.nvalid + 1, (unsigned long long)__popcll(vb));
+  if (a.nvalid && (threadIdx.x & 63) == 0) {      // 64 counter pairs, one per residue of the wave index: no hot address
+    unsigned long long* c = a.nvalid + 2 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63);
+    if (vf) atomicAdd(c + 0, (unsigned long long)__popcll(vf));
+    if (vb) atomicAdd(c + 1, (unsigned long long)__popcll(vb));
   }
   if (!in_range) return;
   const int f = (int)(idx % a.F);

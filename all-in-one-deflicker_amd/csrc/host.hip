@@ -820,7 +820,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(dalloc(&h->flow_rank, (size_t)2 * N)); CCHK(hipMemset(h->flow_rank, 0xff, (size_t)2 * N * 4));
   CCHK(dalloc(&h->scan, (size_t)(N + 255) / 256)); CCHK(hipMemset(h->scan, 0, (size_t)((N + 255) / 256) * 8));
   CCHK(dalloc(&h->live, 1)); CCHK(hipMemset(h->live, 0, 4));
-  CCHK(dalloc(&h->nvalid, 2));
+  CCHK(dalloc(&h->nvalid, 128));
   // schedules
   bool ok = build_main_scheds(h);
   ok = ok && build_sched(h, h->sched[2], {{&M, tiles_of(rows_pre)}});
@@ -882,11 +882,12 @@ int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, co
   }
   if (rc == AF_OK) {
     PackArgs a{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], h->table, h->cfg.resx, h->cfg.resy, h->cfg.number_of_frames, h->nvalid};
-    hipError_t e = hipMemsetAsync(h->nvalid, 0, 16, h->stream);
+    hipError_t e = hipMemsetAsync(h->nvalid, 0, 128 * 8, h->stream);
     int r = e == hipSuccess ? af_launch_pack(&a, h->stream) : (int)e;
     e = r ? (hipError_t)r : hipStreamSynchronize(h->stream);
-    unsigned long long nv[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpy(nv, h->nvalid, 16, hipMemcpyDeviceToHost);
+    unsigned long long nv[2] = {0, 0}, nvs[128];
+    if (e == hipSuccess) e = hipMemcpy(nvs, h->nvalid, sizeof nvs, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) for (int i = 0; i < 64; ++i) { nv[0] += nvs[2 * i]; nv[1] += nvs[2 * i + 1]; }
     if (e != hipSuccess) rc = h->fail(AF_EHIP, "pack table", e);
     else {
       // re-balance launches and dW schedule for the share of valid flow matches of THIS video (the rows are compacted on the device)
@@ -964,7 +965,22 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
   return AF_OK;
 }
 
-int af_set_dw_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->dw_mode = mode; return AF_OK; }
+int af_set_dw_mode(af_handle* h, int mode) {
+  if (!h) return AF_EINVAL;
+  if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA) or 1 (bf16x6)");
+  if (mode == h->dw_mode) return AF_OK;
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic: re-cut the loop's two schedules
+  if (!build_main_scheds(h)) return h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup");
+  for (int i = 0; i < 2; ++i) {
+    HCHK(upload_sched(h->sched[i]));
+    if (h->sched[i].partial_floats > h->partial_cap) {
+      (void)hipFree(h->partial); h->partial = nullptr; h->partial_cap = 0;
+      HCHK(dalloc(&h->partial, h->sched[i].partial_floats)); h->partial_cap = h->sched[i].partial_floats;
+    }
+  }
+  return AF_OK;
+}
 int af_set_mlp_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->mlp_mode = mode; return AF_OK; }
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
 int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
