@@ -18,6 +18,24 @@ AF_DEV float dw_sub(float a, float b) {
   if constexpr (DW_ABL & 8) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // keeps hipcc from SLP-packing into v_pk_add_f32
   return a - b;
 }
+// x - float(one half of a packed bf16 pair) in ONE instruction: v_dot2(c)_f32_bf16 computes h.lo * b.lo + h.hi * b.hi + c with the
+// products exact in fp32; with b = (-1, 0) or (0, -1) that is c - h.lo / c - h.hi, exactly representable (the residual of a
+// round-to-nearest bf16), so no rounding takes place.  Replaces the shift / mask that widens the half plus the subtraction.
+// Measured (tools/dwbench.hip, tools/ablate.hip): bit-identical (tools/splitcheck.hip) but SLOWER — 5 451 instead of 4 820 ticks per
+// k_dw_bf stage, 175-181 k instead of 170 k per chain: the dot instruction is not a single-pass VALU op.  Off; kept as a probe.
+#ifndef DW_SPLIT_DOT2
+#define DW_SPLIT_DOT2 0
+#endif
+// The selector travels in an SGPR the compiler cannot see through: folded to a constant it becomes the inline operand "-1.0",
+// which the instruction reads as the 32-bit pattern 0xbf800000 = (lo 0, hi -1) for BOTH selectors (tools/splitcheck.hip).
+AF_DEV uint32_t dw_sel_lo() { uint32_t s; asm("s_mov_b32 %0, 0x0000bf80" : "=s"(s)); return s; }
+AF_DEV uint32_t dw_sel_hi() { uint32_t s; asm("s_mov_b32 %0, 0xbf800000" : "=s"(s)); return s; }
+AF_DEV float dw_res_lo(uint32_t h, float x) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, dw_sel_lo()), x, false);
+}
+AF_DEV float dw_res_hi(uint32_t h, float x) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, dw_sel_hi()), x, false);
+}
 AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
   DwSplit s;
   if constexpr (DW_ABL & 1) {
@@ -28,9 +46,15 @@ AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
   for (int i = 0; i < 4; ++i) {
     const float a = i < 2 ? lo4[2 * i] : hi4[2 * i - 4], b = i < 2 ? lo4[2 * i + 1] : hi4[2 * i - 3];
     const uint32_t h = dw_pk(a, b);
+#if DW_SPLIT_DOT2
+    const float ra = dw_res_lo(h, a), rb = dw_res_hi(h, b);
+    const uint32_t m = dw_pk(ra, rb);
+    const float qa = dw_res_lo(m, ra), qb = dw_res_hi(m, rb);
+#else
     const float ra = dw_sub(a, __builtin_bit_cast(float, h << 16)), rb = dw_sub(b, __builtin_bit_cast(float, h & 0xffff0000u));
     const uint32_t m = dw_pk(ra, rb);
     const float qa = dw_sub(ra, __builtin_bit_cast(float, m << 16)), qb = dw_sub(rb, __builtin_bit_cast(float, m & 0xffff0000u));
+#endif
     s.h[i] = h; s.m[i] = m; s.l[i] = dw_pk(qa, qb);
   }
   return s;
