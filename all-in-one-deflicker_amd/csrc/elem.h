@@ -42,7 +42,7 @@ struct PrepArgs {
   float* samples;         // [N][16]
   int* counts;            // [2]
   // fg/bg path (stage1_neural_atlas_seg.py): mapping2 sees the same rows except the global-rigidity
-  // neighbours (its own finite-difference distance); the alpha net sees segments 0,1,2,5,6.
+  // neighbours (its own finite-difference distance); the alpha net sees segments 0,1,2 and, behind them, the compacted flow matches.
   float* coords2;         // null in the single-atlas path
   float* x0_tile2;
   float* coordsA;         // [5N pad][4]
@@ -68,7 +68,8 @@ struct LossArgs {
 };
 
 // Loss stack of the fg/bg path (stage1_neural_atlas_seg.py:220-311).  Row layouts: mapping nets as in PrepArgs
-// (segment s, sample n -> row s*N+n); alpha net rows {centre, (x,y+1), (x+1,y), fwd match, bwd match};
+// (fixed segment s, sample n -> row s*N+n; flow matches behind them by rank, see k_prep); alpha net rows {centre, (x,y+1), (x+1,y)} + the
+// same ranked flow matches behind 3N;
 // atlas rows {m1 centre, m1 (x,y+1), m1 (x+1,y), m2 centre, m2 (x,y+1), m2 (x+1,y)}.
 // loss_part sums: 0 rgb, 1 gradient, 2 rigidity1, 3 rigidity2, 4 global rigidity1, 5 global rigidity2,
 // 6 flow1 fwd, 7 flow1 bwd, 8 flow2 fwd, 9 flow2 bwd, 10 alpha-flow fwd, 11 alpha-flow bwd, 12 BCE, 13 sparsity.
