@@ -20,6 +20,10 @@ same draws from the seed alone (tests/test_gpu_c1.py) — the fixture only store
                                     seed 0; means over the seeds 25.525 vs 25.647 dB), single frames by up to 2.5 dB:
                                     the reproducibility floor tests/test_gpu_c1.py builds its tolerances on
 
+    tests/golden/c1_reference_fp64_seed2.npz
+                                    seed 2 with `--double`: the same modules, weights and draws in fp64 (25.30 dB, above the
+                                    four fp32 runs of that seed, 24.93 .. 25.14): where exact arithmetic lands
+
 Build container only (imports /root/reference read-only; ~17 min of CPU per seed):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_c1.py [--seeds 0 1 2] [--threads 6]
@@ -64,12 +68,18 @@ def shipped_config():
     return dict(mod.REFERENCE_CONFIG)
 
 
-def run_seed(seed, c):
+def run_seed(seed, c, double=False):
     video = O.synthetic_video(RESX, RESY, NF, seed=seed)
     torch.manual_seed(seed)
     # stage1_neural_atlas.py:112-128 (mapping first, then atlas)
     rm = IMLP(input_dim=3, output_dim=2, hidden_dim=256, use_positional=False, positional_dim=4, num_layers=6, skip_layers=[], verbose=False)
     ra = IMLP(input_dim=2, output_dim=3, hidden_dim=256, use_positional=True, positional_dim=10, num_layers=8, skip_layers=[4, 7], verbose=False)
+    if double:     # --double: the same fp32 initial weights, draws and video, every operation from here on in fp64 (a diagnostic, not a fixture)
+        rm.double(); ra.double()
+        torch.set_default_dtype(torch.float64)
+        for k, v in list(vars(video).items()):
+            if torch.is_tensor(v) and v.dtype == torch.float32:
+                setattr(video, k, v.double())
     opt = torch.optim.Adam([{"params": list(rm.parameters())}, {"params": list(ra.parameters())}], lr=0.0001)
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
@@ -100,11 +110,12 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c1_reference.npz"))
+    ap.add_argument("--double", action="store_true", help="run the schedule in fp64 from the fp32 initial weights (diagnostic: where exact arithmetic lands)")
     args = ap.parse_args()
     if args.threads > 0:
         torch.set_num_threads(args.threads)
     c = shipped_config()
-    res = [run_seed(s, c) for s in args.seeds]
+    res = [run_seed(s, c, args.double) for s in args.seeds]
     np.savez_compressed(
         args.out, seeds=np.array(args.seeds), resx=RESX, resy=RESY, nframes=NF, iters=ITERS, pretrain_iters=PRETRAIN_ITERS, log_every=LOG_EVERY,
         psnr_pre=np.array([r["psnr_pre"] for r in res]), psnr=np.array([r["psnr"] for r in res]),

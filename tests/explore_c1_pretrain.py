@@ -14,16 +14,18 @@ g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golde
 resx, resy, F, pre_iters = int(g["resx"]), int(g["resy"]), int(g["nframes"]), int(g["pretrain_iters"])
 v = O.synthetic_video(resx, resy, F, seed=seed)
 k = list(g["seeds"]).index(seed)
-for variant in ["base", "ulp1", "ulp2", "ulp3", "dw_fp32", "pre50"]:
+for variant in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["base", "ulp1", "ulp2", "ulp3", "dw_fp32", "pre50"]):
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
     af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
     sds = bench.init_state_dicts(seed)
-    if variant.startswith("ulp"):
-        key = sorted(kk for kk in sds[aiod_amd.NET_MAPPING1] if kk.endswith("weight"))[int(variant[3:]) % 3]
+    if variant.startswith("ulp") or variant.endswith("_ulp"):
+        key = sorted(kk for kk in sds[aiod_amd.NET_MAPPING1] if kk.endswith("weight"))[(int(variant[3:]) if variant[3:].isdigit() else 1) % 3]
         w = sds[aiod_amd.NET_MAPPING1][key].view(-1)
         w[7] = float(np.nextafter(np.float32(w[7].item()), np.float32(10.0)))
-    if variant == "dw_fp32":
+    if variant in ("dw_fp32", "all_fp32", "all_fp32_ulp"):
         af.set_dw_mode(0)
+    if variant in ("mlp_fp32", "all_fp32", "all_fp32_ulp"):
+        af.set_mlp_mode(0)
     for net in af.nets:
         af.load_state_dict(net, sds[net])
     N, P = af.N, F * resx * resy

@@ -106,6 +106,12 @@ def test_configs0_full_schedule_psnr_within_0p1_db_of_reference():
         assert abs(p_end - float(ref_seed[k])) <= tol_seed, (seed, p_end, refs)
         hip.append(p_end)
         hip_dev.append(_run(seed, g, injected=False)[1])
+    f64 = os.path.join(os.path.dirname(GOLDEN), "c1_reference_fp64_seed2.npz")
+    if os.path.exists(f64):     # the reference modules run in fp64 on seed 2 (oracle/make_golden_c1.py --double): where exact arithmetic lands
+        d64 = dict(np.load(f64)); k2 = seeds.index(int(d64["seeds"][0]))
+        print("seed %d in fp64 through the reference's modules: %.4f dB ; reference fp32 %.4f / %.4f ; hip %.4f"
+              % (seeds[k2], float(d64["psnr"][0]), float(g["psnr"][k2]), float(r["psnr"][k2]), hip[k2]))
+        assert abs(hip[k2] - float(d64["psnr"][0])) <= tol_seed
     m5, m3, mh, md = float(np.mean(g["psnr"])), float(np.mean(r["psnr"])), float(np.mean(hip)), float(np.mean(hip_dev))
     print("mean PSNR over seeds %s: hip %.4f dB ; reference %.4f (%d threads), %.4f (%d threads) ; hip - reference %+.4f, %+.4f dB ; "
           "hip with its own device sampler %.4f dB (%+.4f, %+.4f)"
