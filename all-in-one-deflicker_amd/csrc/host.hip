@@ -1173,15 +1173,19 @@ int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
 }
 
 int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg) {
-  // out [min(cap_wg, nwg)][DW_MAXSEG][4] = {job shape (DW_* enum), first row tile, one past the last, job index}, shape -1 = end of list
+  // out [min(cap_wg, nwg)][DW_MAXSEG][4] = {job shape (DW_* enum), first row tile, one past the last, job index}, shape -1 = end of list;
+  // segments of compacted jobs end where k_dw's last launch clipped them (the live row tiles of the last iteration)
   if (!h || which < 0 || which > 3) return AF_EINVAL;
   const Sched& sc = h->sched[which];
+  int live = 0;
+  if (out) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipMemcpy(&live, h->live, 4, hipMemcpyDeviceToHost); }
   if (out) {
     for (int w = 0; w < std::min(cap_wg, sc.nwg); ++w)
       for (int k = 0; k < DW_MAXSEG; ++k) {
         const DwSeg& sg = sc.segs[(size_t)w * DW_MAXSEG + k];
         int32_t* o = out + ((size_t)w * DW_MAXSEG + k) * 4;
         o[0] = sg.job < 0 ? -1 : sc.jobs[sg.job].shape; o[1] = sg.t0; o[2] = sg.t1; o[3] = sg.job;
+        if (sg.job >= 0 && sc.jobs[sg.job].live_rows) o[2] = std::max(sg.t0, std::min(sg.t1, tiles_of(sc.jobs[sg.job].live_base + live)));
       }
   }
   return sc.nwg;
