@@ -30,7 +30,7 @@ def run(argv=None, backend=None, stage1_main=None):
     ap.add_argument("--two_layer", action="store_true")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--concurrent", type=int, default=1, help="videos optimised at the same time on each GPU (own handle and stream each): "
-                    "the kernels of one fill the idle tail rounds of the others, +4 % / +7 % aggregate throughput at 2 / 3 (tools/two_videos.py)")
+                    "the kernels of one fill the idle tail rounds of the others, a few percent more aggregate throughput at 2 or 3 (tools/two_videos.py)")
     args = ap.parse_args(argv)
     import torch
     import torch.distributed as dist

@@ -281,3 +281,14 @@ def test_pipeline_driver_builds_the_reference_command_sequence():
     o = argparse.Namespace(video_name=None, video_frame_folder="clips/abc", fps=12, gpu=0, class_name="person")
     cmds = [c for _, c in R.build_commands(o)]
     assert cmds[0] == "mv abc ./data/test/abc" and "stage1_seg.py --vid_name abc --class_name person --gpu 0" in cmds[1]
+
+
+@pytest.mark.parametrize("script", ["all-in-one-deflicker_amd/stage1.py", "all-in-one-deflicker_amd/stage1_seg.py", "all-in-one-deflicker_amd/run_pipeline.py",
+                                    "all-in-one-deflicker_amd/launch_videos.py", "bench.py"])
+def test_cli_help_renders(script):
+    """argparse formats every help string with %: a literal percent sign in one of them breaks `--help` for the whole CLI."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, script), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "usage" in r.stdout.lower(), r.stderr[-500:]
