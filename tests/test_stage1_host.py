@@ -234,8 +234,10 @@ def test_device_input_builder_equals_opencv_restatement(tmp_path, small_seg_vide
 
 
 @pytest.mark.gpu
-def test_multi_video_launcher_single_rank(tmp_path, small_video, monkeypatch):
-    """launch_videos.py with one rank: two clips through stage1.main on GPU 0, results tree per clip, one JSON summary."""
+@pytest.mark.parametrize("concurrent", [1, 2])
+def test_multi_video_launcher_single_rank(tmp_path, small_video, monkeypatch, concurrent):
+    """launch_videos.py with one rank: two clips through stage1.main on GPU 0, results tree per clip, one JSON summary —
+    one after the other, and both at a time (two host threads, two handles and streams on the same GPU)."""
     import aiod_amd
     from aiod_amd import launch_videos as L
     (tmp_path / "data").mkdir()
@@ -247,9 +249,10 @@ def test_multi_video_launcher_single_rank(tmp_path, small_video, monkeypatch):
     monkeypatch.chdir(tmp_path)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
-    out = L.run(["--vid_names", "clipA", "clipB", "--config", str(tmp_path / "cfg.json"), "--root", str(tmp_path / "data"), "--down", "1", "--seed", "3"])
+    out = L.run(["--vid_names", "clipA", "clipB", "--config", str(tmp_path / "cfg.json"), "--root", str(tmp_path / "data"), "--down", "1", "--seed", "3",
+                 "--concurrent", str(concurrent)])
     assert out["videos"] == 2 and out["n_gpus"] == 1 and set(out["psnr"]) == {"clipA", "clipB"}
-    assert abs(out["psnr"]["clipA"] - out["psnr"]["clipB"]) < 1e-9          # same clip, same seed -> same result
+    assert abs(out["psnr"]["clipA"] - out["psnr"]["clipB"]) < 1e-9          # same clip, same seed -> same result, also when they share the GPU
     for name in ("clipA", "clipB"):
         assert len(list((tmp_path / "results" / name / "stage_1" / "output").glob("*.png"))) == small_video.F
 
