@@ -36,6 +36,10 @@ AF_DEV float dw_res_lo(uint32_t h, float x) {
 AF_DEV float dw_res_hi(uint32_t h, float x) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, dw_sel_hi()), x, false);
 }
+// LEVELS = 3: hi + mid + lo (six products, fp32-faithful).  LEVELS = 2: hi + mid only, for the three-product variant of k_dw
+// (hh + hm + mh, products of 16-bit mantissas: ~2^-17 per product — far inside the distance the fp32 reference's own weight
+// gradients keep from an fp64 twin, which is the acceptance test it ships under, tests/test_gpu_dw_modes.py).
+template <int LEVELS = 3>
 AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
   DwSplit s;
   if constexpr (DW_ABL & 1) {
@@ -48,14 +52,21 @@ AF_DEV DwSplit dw_split8(const f32x4& lo4, const f32x4& hi4) {
     const uint32_t h = dw_pk(a, b);
 #if DW_SPLIT_DOT2
     const float ra = dw_res_lo(h, a), rb = dw_res_hi(h, b);
-    const uint32_t m = dw_pk(ra, rb);
-    const float qa = dw_res_lo(m, ra), qb = dw_res_hi(m, rb);
 #else
     const float ra = dw_sub(a, __builtin_bit_cast(float, h << 16)), rb = dw_sub(b, __builtin_bit_cast(float, h & 0xffff0000u));
-    const uint32_t m = dw_pk(ra, rb);
-    const float qa = dw_sub(ra, __builtin_bit_cast(float, m << 16)), qb = dw_sub(rb, __builtin_bit_cast(float, m & 0xffff0000u));
 #endif
-    s.h[i] = h; s.m[i] = m; s.l[i] = dw_pk(qa, qb);
+    const uint32_t m = dw_pk(ra, rb);
+    s.h[i] = h; s.m[i] = m;
+    if constexpr (LEVELS == 3) {
+#if DW_SPLIT_DOT2
+      const float qa = dw_res_lo(m, ra), qb = dw_res_hi(m, rb);
+#else
+      const float qa = dw_sub(ra, __builtin_bit_cast(float, m << 16)), qb = dw_sub(rb, __builtin_bit_cast(float, m & 0xffff0000u));
+#endif
+      s.l[i] = dw_pk(qa, qb);
+    } else {
+      s.l[i] = 0u;
+    }
   }
   return s;
 }

@@ -171,9 +171,10 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 // ds_read_b128 of the T-layout half tile per operand tile.
 #include "bfsplit.h"
 
-template <int TO, int TI, int TOW, int TIW>
+template <int TO, int TI, int TOW, int TIW, int NPROD = 6>
 AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
                           int a0, int b0, bool store_w, bool store_db) {
+  constexpr int LV = NPROD == 6 ? 3 : 2;                  // split levels: six products need hi + mid + lo, three only hi + mid
   constexpr int A_B = TO * 2048;
   constexpr int NP = (TO + TI) * 128;
   constexpr int NI = (NP + 255) / 256;
@@ -239,11 +240,11 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     DwSplit sa[TOW];
 #pragma unroll
     for (int x = 0; x < TOW; ++x) {
-      sa[x] = dw_split8(ra[cur][x][0], ra[cur][x][1]);
+      sa[x] = dw_split8<LV>(ra[cur][x][0], ra[cur][x][1]);
       const f32x4 t = ra[cur][x][0] + ra[cur][x][1];
       dbacc[x] += (t[0] + t[1]) + (t[2] + t[3]);
     }
-    DwSplit sb = dw_split8(rb[0][0], rb[0][1]);
+    DwSplit sb = dw_split8<LV>(rb[0][0], rb[0][1]);
     dw_wait_vm<(DW_STAGES - 3) * NI>();                                      // stage s+1 has landed (stage s+2 may still be in flight) ...
     dw_barrier();                                        // ... for every wave; every wave holds what it needs of stage s-1
     read_a(cur ^ 1, nslot);
@@ -253,15 +254,17 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
 #pragma unroll
     for (int y = 0; y < TIW; ++y) {
       DwSplit sbn = sb;
-      if (y + 1 < TIW) sbn = dw_split8(rb[y + 1][0], rb[y + 1][1]);
+      if (y + 1 < TIW) sbn = dw_split8<LV>(rb[y + 1][0], rb[y + 1][1]);
       read_b(y, nslot);                                  // column y of stage s was split one region ago: its registers take stage s+1
       if constexpr (!(DW_ABL & 2)) {
+        if constexpr (NPROD == 6) {
 #pragma unroll
-        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.l, acc[x][y]);
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.l, acc[x][y]);
 #pragma unroll
-        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].l, sb.h, acc[x][y]);
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].l, sb.h, acc[x][y]);
 #pragma unroll
-        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].m, sb.m, acc[x][y]);
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].m, sb.m, acc[x][y]);
+        }
 #pragma unroll
         for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.m, acc[x][y]);
 #pragma unroll
@@ -271,7 +274,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
       for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[x].h, sb.h, acc[x][y]);
       if constexpr (!(DW_ABL & 4)) {
 #pragma unroll
-        for (int i = 0; i < 6 * TOW; ++i) {
+        for (int i = 0; i < NPROD * TOW; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -327,6 +330,7 @@ AF_DEV bool dw_clip(const DwJob& jb, DwSeg& sg, float* partial, int tid) {
   return false;
 }
 
+template <int NPROD>
 __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -344,11 +348,11 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
     const DwJob jb = a.jobs[sg.job];
     if (!dw_clip(jb, sg, a.partial, tid)) continue;
     switch (jb.shape) {      // 8x8: each wave a 4x4 block of output tiles (8 operand tiles to read and split per stage, the minimum)
-      case DW_8x8: dw_segment_bf<8, 8, 4, 4>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2); break;
-      case DW_8x2: dw_segment_bf<8, 2, 2, 2>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
-      case DW_8x1: dw_segment_bf<8, 1, 2, 1>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
-      case DW_1x8: dw_segment_bf<1, 8, 1, 2>(jb, sg, a.partial, smem, tid, wave, lane, 0, 2 * wave, true, wave == 0); break;
-      case DW_1x2: dw_segment_bf<1, 2, 1, 1>(jb, sg, a.partial, smem, tid, wave, lane, 0, wave & 1, wave < 2, wave == 0); break;
+      case DW_8x8: dw_segment_bf<8, 8, 4, 4, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2); break;
+      case DW_8x2: dw_segment_bf<8, 2, 2, 2, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_8x1: dw_segment_bf<8, 1, 2, 1, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
+      case DW_1x8: dw_segment_bf<1, 8, 1, 2, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 0, 2 * wave, true, wave == 0); break;
+      case DW_1x2: dw_segment_bf<1, 2, 1, 1, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 0, wave & 1, wave < 2, wave == 0); break;
       default: break;
     }
   }
@@ -383,14 +387,17 @@ __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-// mode 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32); mode 1: bf16x6 split operands on the bf16 matrix pipe
+// mode 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32); mode 1: bf16x6 split operands on the bf16 matrix pipe; mode 2: bf16x3 (hi + mid, three products)
 extern "C" int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL(k_dw, dim3(nwg), dim3(256), DW_LDS, s, *a);
-  else           hipLaunchKernelGGL(k_dw_bf, dim3(nwg), dim3(256), DW_LDS, s, *a);
+  if (mode == 0)      hipLaunchKernelGGL(k_dw, dim3(nwg), dim3(256), DW_LDS, s, *a);
+  else if (mode == 1) hipLaunchKernelGGL(k_dw_bf<6>, dim3(nwg), dim3(256), DW_LDS, s, *a);
+  else                hipLaunchKernelGGL(k_dw_bf<3>, dim3(nwg), dim3(256), DW_LDS, s, *a);
   return (int)hipGetLastError();
 }
 extern "C" int af_dw_init() {
   hipError_t e = hipFuncSetAttribute((const void*)k_dw, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
   if (e != hipSuccess) return (int)e;
-  return (int)hipFuncSetAttribute((const void*)k_dw_bf, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+  e = hipFuncSetAttribute((const void*)k_dw_bf<6>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipFuncSetAttribute((const void*)k_dw_bf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
 }

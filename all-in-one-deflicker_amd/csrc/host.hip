@@ -112,7 +112,7 @@ struct af_handle {
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
-  int dw_mode = 1;                            // k_dw arithmetic: 1 = bf16x6 split operands on the bf16 matrix pipe (dw.hip), 0 = fp32 MFMA
+  int dw_mode = 2;                            // k_dw arithmetic (dw.hip): 2 = bf16x3 (hi + mid bf16 per operand, three products; the default), 1 = bf16x6, 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -305,9 +305,9 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   // narrow shapes (layer 0, skip columns, output layer) are bound by the latency of their 36-40 KB operand tiles, so they do not
   // get cheaper when the 8x8 tiles move to the bf16 matrix pipe:
   //   fp32 MFMA k_dw:  8x8 7.9 us/tile, 8x2 2.4, 8x1 1.6, 1x8 1.6, 1x2 1.2      bf16x6 k_dw_bf:  8x8 5.47, 8x2 2.0, 8x1 1.44, 1x8 1.44, 1x2 0.9
-  static const double kTileCost[2][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 126.0, 91.0, 91.0, 56.0}};
+  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 126.0, 91.0, 91.0, 56.0}, {306.0, 150.0, 132.0, 135.0, 78.0}};
   const double seg_cost = 60.0;
-  auto tile_cost = [&](int j) { return kTileCost[h->dw_mode ? 1 : 0][sc.jobs[j].shape]; };
+  auto tile_cost = [&](int j) { return kTileCost[h->dw_mode][sc.jobs[j].shape]; };
   double work = 0;
   for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
   int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (4.0 * 276.0)));     // at least ~4 full-size row tiles per workgroup
@@ -767,7 +767,8 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (e != hipSuccess) { g_create_error = std::string("af_create: hipSetDevice: ") + hipGetErrorString(e); return AF_EHIP; }
   af_handle* h = new af_handle();
   h->cfg = *cfg; h->device = device_ordinal; h->seg = seg;
-  if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : 1;
+  if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : h->dw_mode;
+  if (const char* e_ = getenv("AF_DW_MODE")) { const int m_ = atoi(e_); if (m_ >= 0 && m_ <= 2) h->dw_mode = m_; }
   if (const char* e_ = getenv("AF_MLP_FP32")) h->mlp_mode = atoi(e_) ? 0 : 1;
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
@@ -967,7 +968,7 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
 
 int af_set_dw_mode(af_handle* h, int mode) {
   if (!h) return AF_EINVAL;
-  if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA) or 1 (bf16x6)");
+  if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
   if (mode == h->dw_mode) return AF_OK;
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
   h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic: re-cut the loop's two schedules

@@ -29,10 +29,12 @@ DW_TILE_BYTES = {"map1": 328 * 1024, "atlas": 512 * 1024, "map2": 200 * 1024, "a
 METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs ref"     # BASELINE.json "metric"
 # launch classes of af_get_timing -> kernel names as rocprofv3 prints them
 MLP_BF = not os.environ.get("AF_MLP_FP32")      # default: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip)
-DW_BF = not os.environ.get("AF_DW_FP32")
+DW_MODE = 0 if os.environ.get("AF_DW_FP32") else int(os.environ.get("AF_DW_MODE", "2"))     # k_dw arithmetic (host.hip): 2 = bf16x3 (default), 1 = bf16x6, 0 = fp32 MFMA
+DW_BF = DW_MODE != 0
+DW_PRODUCTS = {0: 1, 1: 6, 2: 3}[DW_MODE]
 _FWD = "k_mlp_fwd_multi_bf<true>" if MLP_BF else "k_mlp_fwd_multi<true>"
 _BWD = "k_mlp_bwd_multi_bf" if MLP_BF else "k_mlp_bwd_multi"
-KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "dw": "k_dw_bf" if DW_BF else "k_dw",
+KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "dw": ("k_dw_bf<%d>" % DW_PRODUCTS) if DW_BF else "k_dw",
                    "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
 
 
@@ -313,8 +315,8 @@ def main():
         r = {"map1": rows4[0] - inv_per_step, "atlas": rows4[1], "map2": (rows4[2] - inv_per_step) if args.two_layer else 0, "alpha": (rows4[3] - inv_per_step) if args.two_layer else 0}
         return sum(DW_TILE_BYTES[n] * max(r[n], 0) / 32.0 for n in r)
     dw_alg_bytes = sum(dw_bytes(r) for r in rows_k) / K
-    mfma_peak = BF16X6_PEAK_TFLOPS if (MLP_BF and not is_dw) or (DW_BF and is_dw) else FP32_MFMA_PEAK_TFLOPS
-    if is_dw and DW_BF:      # six bf16 products per fp32 product leave this kernel HBM-bound: the roofline is bytes, not flops
+    mfma_peak = (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS if DW_BF else FP32_MFMA_PEAK_TFLOPS) if is_dw else (BF16X6_PEAK_TFLOPS if MLP_BF else FP32_MFMA_PEAK_TFLOPS)
+    if is_dw and DW_BF:      # on the bf16 matrix pipe this kernel's 64 FLOP/B sit under the HBM roof: the roofline is bytes, not flops
         roof = {"bound": "hbm", "achieved": dw_alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": dw_alg_bytes}
     else:
         roof = {"bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s"}
@@ -330,6 +332,10 @@ def main():
                                 "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None,
                                 "frac_of_bf16x6_peak": (fl / ms / 1e9 / BF16X6_PEAK_TFLOPS) if fl > 0 else None}
             if "dw" in cls:
+                if DW_BF and fl > 0:      # this kernel's own arithmetic: DW_PRODUCTS bf16 products per product
+                    by_kernel[kname]["frac_of_bf16x%d_peak" % DW_PRODUCTS] = fl / ms / 1e9 / (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS)
+                    if DW_PRODUCTS != 6:
+                        by_kernel[kname].pop("frac_of_bf16x6_peak", None)
                 by_kernel[kname]["algorithmic_hbm_gbs"] = dw_alg_bytes / (ms / nl * 1e-3) / 1e9
                 by_kernel[kname]["frac_of_hbm_peak"] = by_kernel[kname]["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
 
@@ -355,7 +361,10 @@ def main():
             "metric": METRIC, "value": value, "unit": "sampled points/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x6: operands split into 3 bf16, 6 partial products, fp32 accumulate)" if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
+            "dtype": ("f32 (" + "; ".join(x for x in (
+                "MLP chains bf16x6: operands split into 3 bf16, 6 partial products" if MLP_BF else "",
+                {1: "weight-gradient GEMM bf16x6", 2: "weight-gradient GEMM bf16x3: 2 bf16 per operand, 3 partial products, gradient error against fp64 held to 3x torch-fp32's at full size"}.get(DW_MODE, "")) if x)
+                + "; fp32 accumulate)") if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
                                    "timed iterations %d..%d (global-rigidity rows while i <= 5000); %s"
                                    % (4 if args.two_layer else 1, " (fg/bg dual atlas + alpha MLP)" if args.two_layer else "",

@@ -1,7 +1,9 @@
-"""k_dw computes the weight gradients either on the fp32 matrix pipe (mode 0) or with fp32-faithful bf16x6 split
-operands on the bf16 matrix pipe (mode 1, the default; dw.hip).  The same forward / backward chains feed both, so the two
-reduced gradients differ only by the round-off of the contraction over the row batch: they must agree to fp32
-round-off in the regime the loop runs in (mapping nets pre-trained), at the fixture size and at BASELINE's full size,
+"""k_dw computes the weight gradients on the fp32 matrix pipe (mode 0), with fp32-faithful bf16x6 split operands on the
+bf16 matrix pipe (mode 1) or with two bf16 per operand and three products (mode 2, the default: what round 1's review asked
+to try, shipped under its acceptance rule — gradient error against an fp64 twin at full size no more than 3x torch-fp32's,
+asserted in tests/test_gpu_fullsize.py).  The same forward / backward chains feed all three, so the reduced gradients
+differ only by the round-off of the contraction over the row batch: they must agree to fp32 round-off in the regime
+the loop runs in (mapping nets pre-trained), at the fixture size and at BASELINE's full size,
 single and two-layer.  (From an un-pre-trained init — rigidity ~1e3, row terms cancelling to 1e-3 of their size — ANY two
 fp32 summation orders differ by ~5e-4, the reference's own fp32 gradient is 1e-3 from fp64 there: not used here.)"""
 import numpy as np
@@ -13,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _grads(af, it, inds, sds):
     out = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         af.set_dw_mode(mode)
         for net in af.nets:
             af.load_state_dict(net, sds[net])
@@ -22,7 +24,7 @@ def _grads(af, it, inds, sds):
         af.set_debug(True)
         losses = af.train_steps(it, 1, inds)[0]
         out[mode] = (losses.copy(), {net: af.last_grads(net) for net in af.nets})
-    af.set_dw_mode(1)
+    af.set_dw_mode(2)
     return out
 
 
@@ -49,11 +51,15 @@ def test_dw_modes_agree_at_full_size(two_layer):
         inds = torch.randint(F * resx * resy, (af.N,), generator=g).numpy()
         r = _grads(af, it, inds, sds)
         assert np.array_equal(r[0][0], r[1][0])                          # the loss record does not depend on k_dw
+        assert np.array_equal(r[0][0], r[2][0])
         for net in af.nets:
-            g0, g1 = r[0][1][net], r[1][1][net]
+            g0, g1, g2 = r[0][1][net], r[1][1][net], r[2][1][net]
             rel = np.linalg.norm(g1 - g0) / np.linalg.norm(g0)
-            print("two_layer", two_layer, "iter", it, "net", net, "bf16x6 vs fp32-MFMA gradient rel (L2) %.3g, max abs %.3g (|g|max %.3g)" % (rel, np.abs(g1 - g0).max(), np.abs(g0).max()))
+            rel3 = np.linalg.norm(g2 - g0) / np.linalg.norm(g0)
+            print("two_layer", two_layer, "iter", it, "net", net, "gradient rel (L2) against fp32-MFMA: bf16x6 %.3g, bf16x3 %.3g ; max abs %.3g / %.3g (|g|max %.3g)"
+                  % (rel, rel3, np.abs(g1 - g0).max(), np.abs(g2 - g0).max(), np.abs(g0).max()))
             assert rel < 3e-4, (it, net, rel)      # two fp32-faithful summation orders over 90 000 partly cancelling rows
+            assert rel3 < 3e-4, (it, net, rel3)    # 16-bit-mantissa operands: ~2^-17 per product, averaged over the batch
     af.close()
     del video
     torch.cuda.empty_cache()
@@ -81,8 +87,10 @@ def test_dw_modes_agree_on_ragged_small_batches(golden, small_video):
     tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
     tr.loss_and_grads(0, inds)
     for net, mdl in zip(af.nets, (m, a)):
-        g0, g1, go = r[0][1][net], r[1][1][net], O.flat_grads(mdl)
-        print("net", net, "modes rel %.3g, bf16x6 vs oracle rel %.3g" % (np.linalg.norm(g1 - g0) / np.linalg.norm(g0), np.linalg.norm(g1 - go) / np.linalg.norm(go)))
-        assert np.linalg.norm(g1 - g0) < 3e-4 * np.linalg.norm(g0)
-        assert np.linalg.norm(g1 - go) < 1e-3 * np.linalg.norm(go)
+        g0, g1, g2, go = r[0][1][net], r[1][1][net], r[2][1][net], O.flat_grads(mdl)
+        print("net", net, "modes rel bf16x6 %.3g, bf16x3 %.3g ; against the oracle: bf16x6 %.3g, bf16x3 %.3g"
+              % (np.linalg.norm(g1 - g0) / np.linalg.norm(g0), np.linalg.norm(g2 - g0) / np.linalg.norm(g0),
+                 np.linalg.norm(g1 - go) / np.linalg.norm(go), np.linalg.norm(g2 - go) / np.linalg.norm(go)))
+        assert np.linalg.norm(g1 - g0) < 3e-4 * np.linalg.norm(g0) and np.linalg.norm(g2 - g0) < 3e-4 * np.linalg.norm(g0)
+        assert np.linalg.norm(g1 - go) < 1e-3 * np.linalg.norm(go) and np.linalg.norm(g2 - go) < 1e-3 * np.linalg.norm(go)
     af.close()

@@ -30,7 +30,9 @@ def full():
 
 
 def test_full_size_iteration_matches_oracle(full):
-    """N = 10 000 samples on the 26.5 M-record table: losses within 1e-3 (measured ~1e-5), gradients within 1e-3."""
+    """N = 10 000 samples on the 26.5 M-record table: losses within 1e-3 (measured ~1e-5), and the acceptance rule of the
+    default arithmetic (bf16x6 chains, bf16x3 weight-gradient GEMM): the gradient error against an
+    fp64 twin of the oracle is no more than 3x torch-fp32's own, per net, with and without the global-rigidity rows."""
     import aiod_amd
     from oracle import atlas_oracle as O
     af, video, sds = full
@@ -71,7 +73,7 @@ def test_full_size_iteration_matches_oracle(full):
             n64 = np.linalg.norm(g64)
             e_hip, e_o32 = np.linalg.norm(hg - g64) / n64, np.linalg.norm(og - g64) / n64
             print(it, name, "grad error vs fp64: hip %.3g  torch-fp32 %.3g   hip vs torch-fp32 %.3g" % (e_hip, e_o32, np.linalg.norm(hg - og) / n64))
-            assert e_hip < max(3 * e_o32, 2e-4), (it, name, e_hip, e_o32)
+            assert e_hip < max(3 * e_o32, 1e-5), (it, name, e_hip, e_o32)
         # valid-flow counters equal the oracle's mask gather
         jif = tr.jif_all[:, inds]
         nf = int((v.optical_flows_mask[jif[1], jif[0], jif[2], 0] != 0).sum()); nb = int((v.optical_flows_reverse_mask[jif[1], jif[0], jif[2], 0] != 0).sum())

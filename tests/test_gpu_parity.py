@@ -273,8 +273,8 @@ def test_more_error_paths(golden, small_video):
     assert lib.af_debug_records(h.h, idx.ctypes.data_as(ctypes.c_void_p), 1, out.ctypes.data_as(ctypes.c_void_p)) == -1
     assert lib.af_resize_bilinear(0, None, 0, 4, 4, 3, None, 2, 2, 3, 1, 0, 1.0, 1.0, 0) == -1
     assert lib.af_flow_consistency(0, None, None, 4, 4, None, 1, 0, 1.0, 0) == -1
-    assert lib.af_set_dw_mode(h.h, 2) == -1 and lib.af_set_mlp_mode(h.h, -1) == -1                              # the arithmetic switches know 0 and 1
-    assert lib.af_set_dw_mode(h.h, 0) == 0 and lib.af_set_dw_mode(h.h, 1) == 0                                   # re-cuts the dW schedules both ways
+    assert lib.af_set_dw_mode(h.h, 3) == -1 and lib.af_set_mlp_mode(h.h, -1) == -1                              # the arithmetic switches know 0, 1 (and 2 for k_dw)
+    assert lib.af_set_dw_mode(h.h, 0) == 0 and lib.af_set_dw_mode(h.h, 1) == 0 and lib.af_set_dw_mode(h.h, 2) == 0   # re-cuts the dW schedules every way
     assert lib.af_debug_dw_schedule(h.h, 7, None, 0) < 0                                                         # no such schedule
     l = h.train_steps(0, 1, None, seed=1)                                                                        # and the handle still trains
     assert np.isfinite(l).all()
