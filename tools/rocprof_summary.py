@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import re
 import sys
 
 d = sys.argv[1]
@@ -26,7 +27,7 @@ if cc:
     out.append("")
     out.append("PMC averages per dispatch (kernels of this repo only)")
     for k, cs in agg.items():
-        if not (k.startswith("k_") or "k_mlp" in k):
+        if not re.match(r"^(void )?k_", k):       # this repository's kernels (templated ones print as "void k_...<...>(...)")
             continue
         out.append("  " + k[:70])
         for c, v in sorted(cs.items()):

@@ -6,6 +6,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -15,7 +16,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items() if k.startswith("k_") or "k_mlp" in k}
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items() if re.match(r"^(void )?k_", k)}
 
 
 fe, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
