@@ -7,7 +7,7 @@ SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libatlasfit.so")
 UNITS = ["mlp.hip", "mlpbf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
 HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", os.path.join("..", "..", "include", "atlasfit.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("AF_HIPCC_EXTRA", "").split()     # AF_HIPCC_EXTRA: -D switches of the kernel experiments (tools/experiments/README.md); use with --force
 
 
 def _hipcc():

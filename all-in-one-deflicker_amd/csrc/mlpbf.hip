@@ -72,9 +72,10 @@ AF_DEV f32x4 bf_frag(const char* lane_base, int sl, int T, int lvl) {
 AF_DEV f32x16 bf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+template <int LEVELS = 3>
 AF_DEV DwSplit bf_split_in(const float (&in)[128], int s) {
   const f32x4 lo = {in[8 * s], in[8 * s + 1], in[8 * s + 2], in[8 * s + 3]}, hi = {in[8 * s + 4], in[8 * s + 5], in[8 * s + 6], in[8 * s + 7]};
-  return dw_split8(lo, hi);
+  return dw_split8<LEVELS>(lo, hi);
 }
 template <int N> AF_DEV void bf_sgb() {
 #pragma unroll
@@ -92,36 +93,51 @@ template <int N> AF_DEV void bf_sgb() {
 // An odd k-step publishes the chunk behind its own before its last product group (after_bytes: the size of the chunk
 // behind the whole block, used by k-step 15) and fetches the lo-level fragments of that chunk's first k-step — inside a
 // block only: across layers nothing is carried (bf_enter), so that every layer of the runtime loop runs the same code.
+#ifndef AF_BWD_NPROD
+#define AF_BWD_NPROD 6      // experiment (tools/experiments/README.md): 3 = the backward chain on hi + mid operands, three products
+#endif
 template <int S, bool ZI, class Hook>
 AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& store_hook) {
   constexpr bool NEXT_BF = S != 15;
   constexpr int sl = S & 1;
   constexpr bool last_in_chunk = sl == 1;
+  constexpr bool X3 = ZI && AF_BWD_NPROD == 3;           // ZI marks the backward chain
   f32x4 fm[8], fh[8];
   // ---- group 1: W_lo x B_hi (8 MFMAs); fetch W_mid
 #pragma unroll
-  for (int T = 0; T < 8; ++T) { pin_acc(pp.fl[T]); fm[T] = bf_frag(lane_base, sl, T, 1); }
+  for (int T = 0; T < 8; ++T) { if constexpr (!X3) pin_acc(pp.fl[T]); fm[T] = bf_frag(lane_base, sl, T, 1); }
+  if constexpr (!X3) {
 #pragma unroll
-  for (int T = 0; T < 8; ++T) {
-    if constexpr (ZI && S == 0) {
-      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc[T] = bf_mfma(pp.fl[T], pp.b.h, z);
-    } else {
-      acc[T] = bf_mfma(pp.fl[T], pp.b.h, acc[T]);
+    for (int T = 0; T < 8; ++T) {
+      if constexpr (ZI && S == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[T] = bf_mfma(pp.fl[T], pp.b.h, z);
+      } else {
+        acc[T] = bf_mfma(pp.fl[T], pp.b.h, acc[T]);
+      }
     }
   }
   cs.issue1();
-  bf_sgb<8>();
+  if constexpr (!X3) bf_sgb<8>();
   // ---- group 2: W_mid x (B_mid, B_hi) (16 MFMAs); fetch W_hi; the deferred tile stores of this k-step's feature tile
 #pragma unroll
   for (int T = 0; T < 8; ++T) { pin_acc(fm[T]); fh[T] = bf_frag(lane_base, sl, T, 0); }
+  if constexpr (!X3) {
 #pragma unroll
-  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fm[T], pp.b.m, acc[T]);
+    for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fm[T], pp.b.m, acc[T]);
+  }
 #pragma unroll
-  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fm[T], pp.b.h, acc[T]);
+  for (int T = 0; T < 8; ++T) {
+    if constexpr (X3 && S == 0) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[T] = bf_mfma(fm[T], pp.b.h, z);
+    } else {
+      acc[T] = bf_mfma(fm[T], pp.b.h, acc[T]);
+    }
+  }
   cs.issue1(); cs.issue1();
   store_hook(GIdx<S>{});
-  bf_sgb<16>();
+  bf_sgb<X3 ? 8 : 16>();
   // ---- publish the next chunk (odd k-steps): every read of this chunk has been issued; the slot can be refilled
   const char* nxt_lane = lane_base;
   if constexpr (last_in_chunk) nxt_lane = cs.publish(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
@@ -131,19 +147,22 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
 #pragma unroll
   for (int T = 0; T < 8; ++T) {
     pin_acc(fh[T]);
-    if constexpr (!last_in_chunk) fln[T] = bf_frag(lane_base, 1, T, 2);
-    else if constexpr (NEXT_BF)   fln[T] = bf_frag(nxt_lane, 0, T, 2);
-    else                          fln[T] = pp.fl[T];
+    if constexpr (X3)                  fln[T] = pp.fl[T];
+    else if constexpr (!last_in_chunk) fln[T] = bf_frag(lane_base, 1, T, 2);
+    else if constexpr (NEXT_BF)        fln[T] = bf_frag(nxt_lane, 0, T, 2);
+    else                               fln[T] = pp.fl[T];
   }
-  if constexpr (S + 1 < 16) bn = bf_split_in(in, S + 1);
+  if constexpr (S + 1 < 16) bn = bf_split_in<X3 ? 2 : 3>(in, S + 1);
+  if constexpr (!X3) {
 #pragma unroll
-  for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.l, acc[T]);
+    for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.l, acc[T]);
+  }
 #pragma unroll
   for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.m, acc[T]);
 #pragma unroll
   for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.h, acc[T]);
   cs.issue1(); cs.issue1(); cs.issue1();
-  bf_sgb<24>();
+  bf_sgb<X3 ? 16 : 24>();
 #pragma unroll
   for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
   pp.b = bn;

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dj, &j, sizeof j, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, segs.data(), segs.size() * sizeof(DwSeg), hipMemcpyHostToDevice));
   DwArgs a{dj, ds, partial, nullptr};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 3; ++mode) {
     for (int r = 0; r < 2; ++r) af_launch_dw(&a, nwg, mode, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double fl = (double)NT * 32 * 2.0 * 256 * 256, by = (double)NT * 2 * AF_TILE_F * 4;
 #ifdef DW_CLK     // core clock ticks each workgroup spent (s_memtime): ticks / event time = the shader clock under this load
-    if (mode == 1) {
+    if (mode >= 1) {
       unsigned long long* clk; CK(hipMalloc(&clk, nwg * 16));
       DwArgs ac = a; ac.wg_clock = clk;
       af_launch_dw(&ac, nwg, mode, 0); CK(hipDeviceSynchronize());
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
       printf("mean ticks per workgroup %.0f = %.0f per stage; over the launch time %.0f MHz\n", tk, tk / (2 * per), tk / (ms * 1000));
     }
 #endif
-    printf("DW_ABL=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, cached ? " L2-resident" : "", mode, mode ? "bf16x6" : "fp32 MFMA", per, ms, fl / ms / 1e9, by / ms / 1e9);
+    printf("DW_ABL=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, cached ? " L2-resident" : "", mode, mode == 2 ? "bf16x3" : (mode ? "bf16x6" : "fp32 MFMA"), per, ms, fl / ms / 1e9, by / ms / 1e9);
   }
   return 0;
 }
