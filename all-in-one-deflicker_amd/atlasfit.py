@@ -427,7 +427,8 @@ class AtlasFit:
         self._chk(self.lib.af_set_dw_mode(self.h, int(mode)))
 
     def set_mlp_mode(self, mode):
-        """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check)."""
+        """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check),
+        2 = bf16x6 forward, three-product backward chain (experiment)."""
         self._chk(self.lib.af_set_mlp_mode(self.h, int(mode)))
 
     def set_debug(self, on=True):

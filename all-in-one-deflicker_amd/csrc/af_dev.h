@@ -79,7 +79,7 @@ struct BwdArgs {
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip
 struct MultiFwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; FwdArgs a[AF_MAX_NETS]; };
-struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; };
+struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; int nprod; };      // nprod: 3 selects the three-product chain (mlpbf.hip)
 
 struct DwJob {
   const float* A; const float* B;     // T-layout tensors (dZ_l and X_l)

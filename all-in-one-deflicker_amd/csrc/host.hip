@@ -89,7 +89,8 @@ struct af_handle {
   NetDesc nets[AF_MAX_NETS];
   size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0, sf_bytes = 0, sb_bytes = 0;
   char *img_sf = nullptr, *img_sb = nullptr;   // bf16x6 chain streams
-  int mlp_mode = 1;                            // MLP chains: 1 = hidden layers on the bf16 matrix pipe, fp32-faithful bf16x6 (mlpbf.hip); 0 = fp32 MFMA (mlp.hip)
+  int mlp_mode = 1;                            // MLP chains: 1 = hidden layers on the bf16 matrix pipe, fp32-faithful bf16x6 (mlpbf.hip); 0 = fp32 MFMA (mlp.hip);
+                                               // 2 = as 1 with the backward chain on three products (experiment)
   float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *pre_m = nullptr, *pre_v = nullptr, *grads = nullptr;
   float *img_f = nullptr, *img_b = nullptr, *bias_img = nullptr;
   long long adam_step = 0;
@@ -507,6 +508,7 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   }
   if (m.n == 0) return 0;
   Timer t(h, cls, fl);
+  m.nprod = h->mlp_mode == 2 ? 3 : 6;
   if (h->mlp_mode) LCHK(af_launch_bwd_multi_bf(&m, h->stream));
   else             LCHK(af_launch_bwd_multi(&m, h->stream));
   return 0;
@@ -770,6 +772,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : h->dw_mode;
   if (const char* e_ = getenv("AF_DW_MODE")) { const int m_ = atoi(e_); if (m_ >= 0 && m_ <= 2) h->dw_mode = m_; }
   if (const char* e_ = getenv("AF_MLP_FP32")) h->mlp_mode = atoi(e_) ? 0 : 1;
+  if (const char* e_ = getenv("AF_MLP_MODE")) { const int m_ = atoi(e_); if (m_ >= 0 && m_ <= 2) h->mlp_mode = m_; }
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
   auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
@@ -982,7 +985,12 @@ int af_set_dw_mode(af_handle* h, int mode) {
   }
   return AF_OK;
 }
-int af_set_mlp_mode(af_handle* h, int mode) { if (!h) return AF_EINVAL; if (mode != 0 && mode != 1) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA) or 1 (bf16x6)"); h->mlp_mode = mode; return AF_OK; }
+int af_set_mlp_mode(af_handle* h, int mode) {
+  if (!h) return AF_EINVAL;
+  if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x6 forward, three-product backward chain)");
+  h->mlp_mode = mode;
+  return AF_OK;
+}
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
 int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
 int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset) {

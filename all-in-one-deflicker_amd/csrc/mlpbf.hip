@@ -93,15 +93,14 @@ template <int N> AF_DEV void bf_sgb() {
 // An odd k-step publishes the chunk behind its own before its last product group (after_bytes: the size of the chunk
 // behind the whole block, used by k-step 15) and fetches the lo-level fragments of that chunk's first k-step — inside a
 // block only: across layers nothing is carried (bf_enter), so that every layer of the runtime loop runs the same code.
-#ifndef AF_BWD_NPROD
-#define AF_BWD_NPROD 6      // experiment (tools/experiments/README.md): 3 = the backward chain on hi + mid operands, three products
-#endif
-template <int S, bool ZI, class Hook>
+// NPROD = 3 (backward chain only, af_set_mlp_mode(h, 2); an experiment, not the default): hi + mid operands, three products.
+template <int S, bool ZI, int NPROD, class Hook>
 AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& store_hook) {
   constexpr bool NEXT_BF = S != 15;
   constexpr int sl = S & 1;
   constexpr bool last_in_chunk = sl == 1;
-  constexpr bool X3 = ZI && AF_BWD_NPROD == 3;           // ZI marks the backward chain
+  constexpr bool X3 = NPROD == 3;
+  static_assert(NPROD == 6 || (NPROD == 3 && ZI), "three products are wired for the backward chain only");
   f32x4 fm[8], fh[8];
   // ---- group 1: W_lo x B_hi (8 MFMAs); fetch W_mid
 #pragma unroll
@@ -171,13 +170,13 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
 
 // A whole 256 -> 256 product (16 k-steps = 8 chunks).  On entry the first chunk is published at lane_base (bf_enter has
 // fetched its first fragments); on exit lane_base addresses the published chunk behind the block (after_bytes long).
-template <bool ZI, class Hook, int... Ss>
+template <bool ZI, int NPROD, class Hook, int... Ss>
 AF_DEV void bf_block_impl(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook& hook, std::integer_sequence<int, Ss...>) {
-  (bf_kstep<Ss, ZI>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook), ...);
+  (bf_kstep<Ss, ZI, NPROD>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook), ...);
 }
-template <bool ZI, class Hook>
+template <bool ZI, int NPROD = 6, class Hook>
 AF_DEV void bf_block(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& hook) {
-  bf_block_impl<ZI>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook, std::make_integer_sequence<int, 16>{});
+  bf_block_impl<ZI, NPROD>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook, std::make_integer_sequence<int, 16>{});
 }
 // entering a block: the lo-level fragments and the split B operand of its first k-step
 AF_DEV void bf_enter(BfPipe& pp, const float (&in)[128], const char* lane_base) {
@@ -358,7 +357,7 @@ template <int... Es> AF_DEV void bf_mask_all(float (&in)[128], const f32x16 (&ac
 
 // ------------------------------------------------------------------------------------------------
 // Backward dX chain on the same scheme: dZ_{l-1} = (W_l^T dZ_l) . relu'(Z_{l-1}) with the bf16x3 image of W_l^T.
-template <class NS>
+template <class NS, int NPROD = 6>
 AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,7 +413,7 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
   for (int l = NS::NL - 2; l >= 1; --l) {
     bf_enter(pp, in, lane_base);
     // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
-    bf_block<true>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), hook_store);
+    bf_block<true, NPROD>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), hook_store);
     mask_out(l);
   }
   lane_base -= lane_off;
@@ -493,6 +492,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
   AF_CLK_MARK(1);
 }
 
+// the same chain on three products (see bf_kstep)
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf3(MultiBwd m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0, base = 0;
+  const int wg = blockIdx.x;
+  while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
+  switch (m.net[s]) {
+    case AF_NET_MAP1:  mlp_bwd_body_bf<NsMap1, 3>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  mlp_bwd_body_bf<NsMap2, 3>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: mlp_bwd_body_bf<NsAtlas, 3>(m.a[s], wg - base, smem); break;
+    default:           mlp_bwd_body_bf<NsAlpha, 3>(m.a[s], wg - base, smem); break;
+  }
+}
+
 extern "C" int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s) {
   int tot = 0;
   for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
@@ -505,7 +518,8 @@ extern "C" int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s) {
   int tot = 0;
   for (int i = 0; i < m->n; ++i) { tot += (m->a[i].NT - m->a[i].tile0 + 3) / 4; m->wg_end[i] = tot; }
   if (tot <= 0) return 0;
-  hipLaunchKernelGGL(k_mlp_bwd_multi_bf, dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
+  if (m->n > 0 && m->nprod == 3) hipLaunchKernelGGL(k_mlp_bwd_multi_bf3, dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
+  else                           hipLaunchKernelGGL(k_mlp_bwd_multi_bf, dim3(tot), dim3(256), AF_LDS_BYTES_BF, s, *m);
   return (int)hipGetLastError();
 }
 // chunk sizes of the bf16 streams for the host planner: which = 0 fwd layer 0, 1 bf16 hidden chunk (x8 per layer), 2 skip columns,
@@ -527,7 +541,7 @@ extern "C" int af_mlp_chunk_bytes_bf(int net, int which) {
 extern "C" int af_mlp_bf_init() {
   hipError_t e = hipSuccess;
 #define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES_BF); if (r != hipSuccess) e = r; } while (0)
-  AF_ATTR((k_mlp_fwd_multi_bf<true>)); AF_ATTR((k_mlp_fwd_multi_bf<false>)); AF_ATTR(k_mlp_bwd_multi_bf);
+  AF_ATTR((k_mlp_fwd_multi_bf<true>)); AF_ATTR((k_mlp_fwd_multi_bf<false>)); AF_ATTR(k_mlp_bwd_multi_bf); AF_ATTR(k_mlp_bwd_multi_bf3);
 #undef AF_ATTR
   return (int)e;
 }

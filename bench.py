@@ -28,12 +28,13 @@ HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E 8 TB/s spec (6.3 TB/s
 DW_TILE_BYTES = {"map1": 328 * 1024, "atlas": 512 * 1024, "map2": 200 * 1024, "alpha": 460 * 1024}
 METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs ref"     # BASELINE.json "metric"
 # launch classes of af_get_timing -> kernel names as rocprofv3 prints them
-MLP_BF = not os.environ.get("AF_MLP_FP32")      # default: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip)
+MLP_MODE = 0 if os.environ.get("AF_MLP_FP32") else int(os.environ.get("AF_MLP_MODE", "1"))     # 1: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip); 2: backward chain on three products (experiment)
+MLP_BF = MLP_MODE != 0
 DW_MODE = 0 if os.environ.get("AF_DW_FP32") else int(os.environ.get("AF_DW_MODE", "2"))     # k_dw arithmetic (host.hip): 2 = bf16x3 (default), 1 = bf16x6, 0 = fp32 MFMA
 DW_BF = DW_MODE != 0
 DW_PRODUCTS = {0: 1, 1: 6, 2: 3}[DW_MODE]
 _FWD = "k_mlp_fwd_multi_bf<true>" if MLP_BF else "k_mlp_fwd_multi<true>"
-_BWD = "k_mlp_bwd_multi_bf" if MLP_BF else "k_mlp_bwd_multi"
+_BWD = ("k_mlp_bwd_multi_bf3" if MLP_MODE == 2 else "k_mlp_bwd_multi_bf") if MLP_BF else "k_mlp_bwd_multi"
 KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "dw": ("k_dw_bf<%d>" % DW_PRODUCTS) if DW_BF else "k_dw",
                    "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
 
@@ -362,7 +363,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (" + "; ".join(x for x in (
-                "MLP chains bf16x6: operands split into 3 bf16, 6 partial products" if MLP_BF else "",
+                ("MLP chains bf16x6: operands split into 3 bf16, 6 partial products" + (" (EXPERIMENT: backward chain on 3 products)" if MLP_MODE == 2 else "")) if MLP_BF else "",
                 {1: "weight-gradient GEMM bf16x6", 2: "weight-gradient GEMM bf16x3: 2 bf16 per operand, 3 partial products, gradient error against fp64 held to 3x torch-fp32's at full size"}.get(DW_MODE, "")) if x)
                 + "; fp32 accumulate)") if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "

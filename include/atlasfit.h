@@ -146,7 +146,9 @@ int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
  * against each other in tests/test_gpu_dw_modes.py.  Env AF_DW_MODE=<m> at af_create; AF_DW_FP32=1 selects 0. */
 int af_set_dw_mode(af_handle* h, int mode);
 /* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
- * = bf16x6, 0 = fp32 matrix pipe.  Env AF_MLP_FP32=1 selects 0.  pre_train_mapping always runs the fp32 16-row chains. */
+ * = bf16x6, 0 = fp32 matrix pipe, 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16
+ * operands — a measured experiment, not a default.  Env AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.
+ * pre_train_mapping always runs the fp32 16-row chains. */
 int af_set_mlp_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
