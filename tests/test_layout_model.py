@@ -128,3 +128,17 @@ def test_imlp_shapes_follow_the_config_and_match_the_reference_counts():
     other = A.default_config(64, 48, 4, number_of_channels_atlas=128, number_of_layers_mapping1=4, positional_encoding_num_atlas=6)
     assert A.imlp_shapes(A.NET_ATLAS, other)[0] == (128, 24) and len(A.imlp_shapes(A.NET_MAPPING1, other)) == 4
     assert sum(o * k + o for o, k in A.imlp_shapes(A.NET_ATLAS, other)) != 416379
+
+
+def test_committed_traffic_summary_names_the_kernels_bench_reports():
+    """bench.py looks the dominant kernel's measured HBM traffic up by kernel NAME in profiles/r2_traffic.json (written by
+    tools/traffic_from_pmc.py from the rocprofv3 PMC passes): every hot kernel of the default arithmetic must be in it."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "r2_traffic.json")))
+    for cls in ("fwd_1", "bwd_1", "dw"):
+        name = bench.KERNEL_OF_CLASS[cls]
+        assert name in tj["kernels"], (name, sorted(tj["kernels"]))
+        assert tj["kernels"][name]["hbm_bytes"] > 0
