@@ -290,9 +290,10 @@ class AtlasFit:
         self.loss_width = int(self.lib.af_loss_width(h))
         for net in self.nets:                       # the Python view of the architecture must be the library's
             n = sum(o * k + o for o, k in imlp_shapes(net, cfg))
-            if n != self.param_count(net):
+            built = self.param_count(net)
+            if n != built:
                 self.close()
-                raise AtlasFitError(-1, "net %d: config describes %d parameters, libatlasfit.so built %d" % (net, n, self.param_count(net)))
+                raise AtlasFitError(-1, "net %d: config describes %d parameters, libatlasfit.so built %d" % (net, n, built))
 
     def close(self):
         if getattr(self, "h", None):

@@ -51,8 +51,10 @@ struct PrepArgs {
   // matches of the batch are ranked sample-major (fwd before bwd) by a decoupled look-back scan over the blocks of this
   // launch and written behind the fixed segments, row flow_base + rank (alpha net: 3N + rank).
   int* flow_rank;         // [N][2] rank of the sample's fwd / bwd match among the valid matches, -1 when invalid
-  unsigned long long* scan;   // [gridDim.x] (epoch << 32 | matches of the block)
+  unsigned long long* scan;   // [gridDim.x] (epoch << 32 | matches of the block), indexed by the block's TICKET
   uint32_t epoch;         // unique per launch: a stale entry of an earlier launch can never satisfy the look-back
+  unsigned long long* ticket; // [1] monotonic over the handle's k_prep launches: a block's virtual id = its ticket - ticket_base
+  unsigned long long ticket_base;   // blocks launched by all earlier k_prep launches of the handle
   int* live;              // [1] valid matches of the batch = live rows behind flow_base
 };
 

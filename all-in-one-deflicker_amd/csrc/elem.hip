@@ -170,7 +170,15 @@ AF_DEV void put_row(const PrepArgs& a, int seg, int aseg, int n, float x, float 
 __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   __shared__ int wsum[4];
   __shared__ int red_i[4];
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // Virtual block id from an atomic ticket, not blockIdx.x: the look-back below waits for every block with a SMALLER id, and
+  // a block that holds a ticket has started, so all of its predecessors are resident or finished whatever order the
+  // hardware dispatched the grid in (HIP guarantees none) and however many blocks the launch has.  The ticket counter is
+  // monotonic over the handle's launches (never reset); the host passes the count at the start of this launch.
+  if (threadIdx.x == 0) red_i[0] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
+  __syncthreads();
+  const int vblk = red_i[0];
+  __syncthreads();
+  const int n = vblk * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int vf = 0, vb = 0;
   int x = 0, y = 0, f = 0;
@@ -218,19 +226,21 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   for (int w = 0; w < wave; ++w) in_block += wsum[w];
   const int btot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   if (threadIdx.x == 0)
-    __hip_atomic_store(a.scan + blockIdx.x, ((unsigned long long)a.epoch << 32) | (unsigned)btot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  int pre = 0;      // look back: every block in front of this one is resident or finished (the grid is far smaller than the chip)
-  for (int b = threadIdx.x; b < (int)blockIdx.x; b += blockDim.x) {
-    unsigned long long v;
-    do { v = __hip_atomic_load(a.scan + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != a.epoch);
-    pre += (int)(uint32_t)v;
-  }
+    __hip_atomic_store(a.scan + vblk, ((unsigned long long)a.epoch << 32) | (unsigned)btot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  int pre = 0;      // look back (one wave polls): every block with a smaller ticket has started, see above
+  if (wave == 0) {
+    for (int b = lane; b < vblk; b += 64) {
+      unsigned long long v;
+      do { v = __hip_atomic_load(a.scan + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != a.epoch);
+      pre += (int)(uint32_t)v;
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
-  if (lane == 0) red_i[wave] = pre;
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    if (lane == 0) red_i[0] = pre;
+  }
   __syncthreads();
-  pre = (red_i[0] + red_i[1]) + (red_i[2] + red_i[3]);
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *a.live = pre + btot;
+  pre = red_i[0];
+  if (vblk == (int)gridDim.x - 1 && threadIdx.x == 0) *a.live = pre + btot;
   if (n < a.N) {
     const int rank_f = pre + in_block, rank_b = rank_f + vf;
     const size_t base = (size_t)(a.nseg - 2) * a.N, abase = (size_t)3 * a.N;

@@ -103,7 +103,7 @@ struct af_handle {
   int* nan_flag = nullptr;                    // sticky, set on the device by k_adam: a non-finite parameter, a NaN loss term or an empty flow-match set
   int cur_nseg = 0;
   // compaction of the flow-match rows (k_prep): per-sample ranks, look-back scan slots, live match count, launch epoch
-  int* flow_rank = nullptr; unsigned long long* scan = nullptr; int* live = nullptr; uint32_t prep_epoch = 0;
+  int* flow_rank = nullptr; unsigned long long* scan = nullptr; int* live = nullptr; uint32_t prep_epoch = 0; unsigned long long prep_tickets = 0;
   unsigned long long* nvalid = nullptr; double p_valid[2] = {1.0, 1.0};     // share of the video's pixels with a valid fwd / bwd match
   int plan_flow_rows = 0;                                                   // flow-match rows the launches and the dW schedule are balanced for
   // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
@@ -113,7 +113,7 @@ struct af_handle {
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
-  int dw_mode = 2;                            // k_dw arithmetic (dw.hip): 2 = bf16x3 (hi + mid bf16 per operand, three products; the default), 1 = bf16x6, 0 = fp32 MFMA
+  int dw_mode = 1;                            // k_dw arithmetic (dw.hip): 1 = bf16x6 (fp32-faithful, the default), 2 = bf16x3 (hi + mid bf16 per operand, three products; opt-in), 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
   int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -586,6 +586,7 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
     p.coords = M.coords; p.x0_tile = M.x0_tile; p.samples = h->samples; p.counts = h->counts;
     p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
+    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets; h->prep_tickets += (unsigned long long)((N + 255) / 256);
     LCHK(af_launch_prep(&p, h->stream));
   }
   // Launch 1: the whole rounds of the mapping batch (they hold the 3N rows the atlas reads).  Launch 2: the atlas
@@ -645,6 +646,7 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     p.coords = M1.coords; p.x0_tile = M1.x0_tile; p.samples = h->samples; p.counts = h->counts;
     p.coords2 = M2.coords; p.x0_tile2 = M2.x0_tile; p.coordsA = AL.coords; p.d_global2 = c.global_rigidity_derivative_amount_bg;
     p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
+    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets; h->prep_tickets += (unsigned long long)((N + 255) / 256);
     LCHK(af_launch_prep(&p, h->stream));
   }
   // Launch 1: alpha, mapping1, mapping2 (longest chains first, so the launch drains on the short ones).
@@ -822,7 +824,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(dalloc(&h->counts, 2)); CCHK(hipMemset(h->counts, 0, 8));
   CCHK(dalloc(&h->nan_flag, 1)); CCHK(hipMemset(h->nan_flag, 0, 4));
   CCHK(dalloc(&h->flow_rank, (size_t)2 * N)); CCHK(hipMemset(h->flow_rank, 0xff, (size_t)2 * N * 4));
-  CCHK(dalloc(&h->scan, (size_t)(N + 255) / 256)); CCHK(hipMemset(h->scan, 0, (size_t)((N + 255) / 256) * 8));
+  CCHK(dalloc(&h->scan, (size_t)(N + 255) / 256 + 1)); CCHK(hipMemset(h->scan, 0, (size_t)((N + 255) / 256 + 1) * 8));   // + the ticket counter of k_prep
   CCHK(dalloc(&h->live, 1)); CCHK(hipMemset(h->live, 0, 4));
   CCHK(dalloc(&h->nvalid, 128));
   // schedules
@@ -974,9 +976,12 @@ int af_set_dw_mode(af_handle* h, int mode) {
   if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
   if (mode == h->dw_mode) return AF_OK;
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
-  h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic: re-cut the loop's two schedules
-  if (!build_main_scheds(h)) return h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup");
-  for (int i = 0; i < 2; ++i) {
+  h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic: re-cut every schedule (loop and pre-train)
+  bool ok = build_main_scheds(h);
+  ok = ok && build_sched(h, h->sched[2], {{&h->nets[AF_NET_MAP1], tiles_of(h->cfg.pretrain_batch)}});
+  if (h->seg) ok = ok && build_sched(h, h->sched[3], {{&h->nets[AF_NET_MAP2], tiles_of(h->cfg.pretrain_batch)}});
+  if (!ok) return h->fail(AF_EINVAL, "dW schedule needs more than DW_MAXSEG segments per workgroup");
+  for (int i = 0; i < (h->seg ? 4 : 3); ++i) {
     HCHK(upload_sched(h->sched[i]));
     if (h->sched[i].partial_floats > h->partial_cap) {
       (void)hipFree(h->partial); h->partial = nullptr; h->partial_cap = 0;

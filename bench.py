@@ -30,7 +30,7 @@ METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs
 # launch classes of af_get_timing -> kernel names as rocprofv3 prints them
 MLP_MODE = 0 if os.environ.get("AF_MLP_FP32") else int(os.environ.get("AF_MLP_MODE", "1"))     # 1: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip); 2: backward chain on three products (experiment)
 MLP_BF = MLP_MODE != 0
-DW_MODE = 0 if os.environ.get("AF_DW_FP32") else int(os.environ.get("AF_DW_MODE", "2"))     # k_dw arithmetic (host.hip): 2 = bf16x3 (default), 1 = bf16x6, 0 = fp32 MFMA
+DW_MODE = 0 if os.environ.get("AF_DW_FP32") else int(os.environ.get("AF_DW_MODE", "1"))     # k_dw arithmetic (host.hip): 1 = bf16x6 (fp32-faithful, the default and the headline), 2 = bf16x3 (opt-in, narrower than fp32), 0 = fp32 MFMA
 DW_BF = DW_MODE != 0
 DW_PRODUCTS = {0: 1, 1: 6, 2: 3}[DW_MODE]
 _FWD = "k_mlp_fwd_multi_bf<true>" if MLP_BF else "k_mlp_fwd_multi<true>"
@@ -180,6 +180,83 @@ def shard_for_rank(rank, world, n_videos=None):
     return list(range(rank, n_videos, world))
 
 
+def self_spawn(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher (no RANK in the environment): re-exec under torch.distributed.run,
+    one rank per GPU of this node, rendezvous on 127.0.0.1 at a free port.  The ranks then take the normal path."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(backend, args):
+    """AF_BENCH_DRY_RUN=<backend> (tests, CPU): everything of the multi-rank launch path that does not need a GPU - rendezvous,
+    process group, video shard of the rank, the barrier-bracketed timed region with its MAX all-reduce - then one JSON line."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend)
+    assert args.gpus == world, (args.gpus, world)
+    dt = timed_region(lambda: time.sleep(0.01 * (rank + 1)), lambda: None, dist if world > 1 else None, torch.device("cpu"))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "backend": backend, "n_gpus": world, "video_of_rank0": shard_for_rank(0, world), "max_region_s": dt}))
+
+
+def model_rows(it, N, p_valid, two_layer, stop_global=5000):
+    """MLP rows per net (map1, atlas, map2, alpha) of iteration `it` when a share p_valid of the 2N flow matches is valid
+    (k_prep compacts them): the row model behind the HBM byte model below.  No GPU needed."""
+    live = 2.0 * N * p_valid
+    m = 5 * N + (2 * N if it <= stop_global else 0) + live
+    return (m, (6 if two_layer else 3) * N, m if two_layer else 0, (3 * N + live) if two_layer else 0)
+
+
+# bytes a chain moves through HBM per row (DESIGN.md 2.1): per hidden layer one 1 KB T-layout tile row of X_l (forward) or dZ_l
+# (backward) + 32 B of sign bits written (forward) / read (backward); the PE tile of the atlas / alpha nets; coordinates in, outputs out
+CHAIN_HIDDEN = {"map1": 5, "atlas": 7, "map2": 3, "alpha": 7}
+CHAIN_PE_BYTES = {"map1": 0, "atlas": 160, "map2": 0, "alpha": 128}
+# bf16 h/m/l weight stream of one orientation: 256x256 hidden layers x 3 levels x 2 B; every XCD's L2 (8 of them) fetches it once per launch
+CHAIN_STREAM_BYTES = {"map1": 4 * 393216, "atlas": 6 * 393216, "map2": 2 * 393216, "alpha": 6 * 393216}
+
+
+def hbm_model_bytes(kernel, rows4, launches_per_step):
+    """Expected HBM bytes per launch of a hot kernel from the layouts alone (what DESIGN.md 2.1 / 2.2 say must move), for
+    the rows of one step.  bench.py quotes a committed PMC measurement as `traffic` only while it agrees with this model."""
+    r = dict(zip(("map1", "atlas", "map2", "alpha"), rows4))
+    if kernel.startswith("k_dw"):
+        return sum(DW_TILE_BYTES[n] * r[n] / 32.0 for n in r) / launches_per_step
+    per_row = {n: CHAIN_HIDDEN[n] * (1024 + 32) + CHAIN_PE_BYTES[n] + 32 for n in r}
+    if kernel.startswith("k_mlp_bwd"):
+        per_row["map1"] += 128; per_row["map2"] += 128     # dz of layer 0's three inputs is not stored; the x0 tile is read by k_dw, not here
+    streams = 8 * sum(CHAIN_STREAM_BYTES[n] * (2 if n == "map1" else 1) for n in r if r[n] > 0)     # mapping1 has tiles in both launches of a direction
+    return (sum(per_row[n] * r[n] for n in r) + streams) / launches_per_step
+
+
+def committed_traffic(kernel, model_bytes, tol=0.12):
+    """The newest profiles/r*_traffic.json that holds `kernel`: (bytes per launch, source) when the measurement agrees
+    with the layout model within `tol`, else (None, why)."""
+    import glob
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), key=lambda q: [int(x) for x in re.findall(r"r(\d+)", os.path.basename(q))[:1]] + [q], reverse=True)
+    for tpath in paths:
+        try:
+            tj = json.load(open(tpath))
+            b = tj["kernels"][kernel]["hbm_bytes"]
+        except Exception:
+            continue
+        rel = os.path.relpath(tpath, ROOT)
+        if model_bytes > 0 and abs(b / model_bytes - 1.0) <= tol:
+            return b, "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; %s); layout model %.4g B, measured/model %.3f" % (rel, tj["correction"], model_bytes, b / model_bytes)
+        return None, "%s holds %.4g B for this kernel but the layout model of this run says %.4g B (ratio %.3f): stale or another workload, not quoted" % (rel, b, model_bytes, b / model_bytes if model_bytes else float("nan"))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +276,10 @@ def main():
                     "per pixel: real RAFT masks are far from all-valid, and only valid rows are credited as algorithmic work (loss_utils.py:326-356)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:         # bare `python bench.py --gpus N`: spawn the N ranks ourselves
+        return self_spawn(args.gpus, sys.argv[1:])
+    if os.environ.get("AF_BENCH_DRY_RUN"):
+        return dry_run(os.environ["AF_BENCH_DRY_RUN"], args)
     import torch
     import aiod_amd
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,7 +292,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert args.gpus == world, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node == --gpus (or bare, without RANK in the environment)" % (args.gpus, world)
 
     cfg = aiod_amd.default_config(args.resx, args.resy, args.frames, two_layer=args.two_layer)
     N = cfg.samples_batch
@@ -240,7 +321,9 @@ def main():
     switch = cfg.stop_global_rigidity + 1                           # first iteration without the global term
     first = max(0, switch - K // 2) if args.first_iter < 0 else args.first_iter
     classes = af.TIMING_NAMES      # prep, fwd_1, fwd_2, loss, bwd_1, bwd_2, dw, adam (include/atlasfit.h: af_get_timing)
-
+    by_name = {}
+    for c in classes:
+        by_name.setdefault(KERNEL_OF_CLASS[c], []).append(c)
 
     # ---- warm-up (W untimed steps, all kernel classes timed to find the dominant one)
     af.set_timing(0xFFFF)
@@ -249,10 +332,7 @@ def main():
         af.train_steps(wfirst, W, None, seed=rank, return_losses=False)
     tw = af.timing(reset=True)
     # the dominant KERNEL (by name, all of its launches in a step: k_mlp_fwd_multi = fwd_1 + fwd_2, ...), not the dominant launch
-    by_name = {}
-    for c in classes:
-        by_name.setdefault(KERNEL_OF_CLASS[c], []).append(c)
-    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["dw"]
+    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["bwd_1"]
     dom_classes = by_name[dom]
     af.set_timing(sum(1 << classes.index(c) for c in dom_classes))   # events only around the dominant kernel's launches
 
@@ -275,7 +355,7 @@ def main():
             h2.train_steps(wfirst, W, None, seed=rank + v, return_losses=False)
         extra.append(h2)
 
-    # ---- timed region: EXACTLY K steps (of every video on this GPU)
+    # ---- timed region: EXACTLY K steps (of every video on this GPU), the default (fp32-faithful) arithmetic
     got = {}
 
     def run_all():
@@ -288,9 +368,28 @@ def main():
             t.join()
     dt = timed_region(run_all, torch.cuda.synchronize, dist if world > 1 else None, dev)
     tk = af.timing(reset=True)
-    # Rows of the flow-match segments whose consistency mask is 0 are computed but masked out (static row counts, no
-    # compaction); the reference would not evaluate them (loss_utils.py:326-356).  The algorithmic
-    # FLOP counts below therefore charge only the measured valid fractions p_f, p_b.
+
+    # ---- per-kernel pass (NOT the timed region): the same K iterations once more, HIP events around every launch, clocks as
+    # hot as the timed region left them.  Its per-step sum exceeds ms_per_step by the event overhead; `by_kernel` says so.
+    af.set_timing(0xFFFF)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    af.train_steps(first, K, None, seed=rank + 50, return_losses=False)
+    torch.cuda.synchronize(); dt_all_events = time.perf_counter() - t0
+    ta = af.timing(reset=True)
+    af.set_timing(0)
+
+    # ---- second value, never the headline: the same K steps with the weight-gradient GEMM on three bf16 products (narrower
+    # than the reference's fp32; af_set_dw_mode(h, 2)), timed by the same rule
+    dt3 = None
+    if DW_MODE == 1 and not extra:
+        af.set_dw_mode(2)
+        af.train_steps(max(0, first - 5), 5, None, seed=rank + 60, return_losses=False)
+        dt3 = timed_region(lambda: af.train_steps(first, K, None, seed=rank + 61, return_losses=False), torch.cuda.synchronize, dist if world > 1 else None, dev)
+        af.set_dw_mode(1)
+
+    # Only valid flow matches are evaluated (k_prep compacts them like the reference's torch.where); the library
+    # accumulates FLOPs per launch from the planned rows, so the work of the rows behind the live count is taken out here
+    # from the measured valid counts.
     L = got["losses"]
     nv = L[:, -4:-2] if args.two_layer else L[:, 6:8]              # (#valid fwd, #valid bwd) per iteration
     FWD = {"map1": 526848.0, "map2": 264704.0, "alpha": 802304.0}; DX = {"map1": 525312.0, "map2": 263168.0, "alpha": 786944.0}
@@ -298,24 +397,26 @@ def main():
     nets_inv = ("map1", "map2", "alpha") if args.two_layer else ("map1",)
     masked_step_flops = inv * sum(2 * FWD[n] + DX[n] for n in nets_inv)          # fwd + dW + dX of rows the reference skips
     masked_dw_flops = inv * sum(FWD[n] for n in nets_inv)
+    inv_per_step = inv / K
+    rows_k = [af.step_work(first + k)[0] for k in range(K)]             # rows per net (NET_* order: map1, atlas, map2, alpha)
 
-    # ---- roofline of the dominant kernel: algorithmic FLOPs per launch (accumulated by the library from the rows each
-    # launch covered) / mean HIP-event duration over the timed region
+    def live_rows(rows4):     # rows of one step with the dead (invalid-match) rows removed
+        return (rows4[0] - inv_per_step, rows4[1], (rows4[2] - inv_per_step) if args.two_layer else 0, (rows4[3] - inv_per_step) if args.two_layer else 0)
+    rows_mean = tuple(sum(live_rows(r)[j] for r in rows_k) / K for j in range(4))
+    dw_alg_bytes = hbm_model_bytes("k_dw", rows_mean, 1)           # algorithmic = every operand tile of every layer read once
+
+    def masked_of(kname, cls):
+        if "dw" in cls:
+            return masked_dw_flops
+        return inv * (sum(FWD[n] for n in nets_inv) if kname.startswith("k_mlp_fwd") else sum(DX[n] for n in nets_inv)) if kname.startswith("k_mlp") else 0.0
+
+    # ---- roofline of the dominant kernel: algorithmic FLOPs / bytes per launch over the mean HIP-event duration of the TIMED region
     n_launch = max(sum(tk[c][1] for c in dom_classes), 1)
     dom_ms = sum(tk[c][0] for c in dom_classes) / n_launch
     is_dw = "dw" in dom_classes
-    # masked flow rows inside the MLP launches: fwd / dX work of rows the reference would not evaluate (all in the mapping nets + alpha)
-    masked_mlp = inv * (sum(FWD[n] for n in nets_inv) if dom.startswith("k_mlp_fwd") else sum(DX[n] for n in nets_inv)) if not is_dw else 0.0
-    flops_launch = (sum(tk[c][2] for c in dom_classes) - (masked_dw_flops if is_dw else masked_mlp)) / n_launch
+    flops_launch = (sum(tk[c][2] for c in dom_classes) - masked_of(dom, dom_classes)) / n_launch
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
-    # algorithmic HBM bytes of k_dw per step: every operand tile of every layer read once, rows the reference does not evaluate excluded
-    rows_k = [af.step_work(first + k)[0] for k in range(K)]             # rows per net (NET_* order: map1, atlas, map2, alpha)
-    inv_per_step = inv / K
-    def dw_bytes(rows4):
-        r = {"map1": rows4[0] - inv_per_step, "atlas": rows4[1], "map2": (rows4[2] - inv_per_step) if args.two_layer else 0, "alpha": (rows4[3] - inv_per_step) if args.two_layer else 0}
-        return sum(DW_TILE_BYTES[n] * max(r[n], 0) / 32.0 for n in r)
-    dw_alg_bytes = sum(dw_bytes(r) for r in rows_k) / K
     mfma_peak = (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS if DW_BF else FP32_MFMA_PEAK_TFLOPS) if is_dw else (BF16X6_PEAK_TFLOPS if MLP_BF else FP32_MFMA_PEAK_TFLOPS)
     if is_dw and DW_BF:      # on the bf16 matrix pipe this kernel's 64 FLOP/B sit under the HBM roof: the roofline is bytes, not flops
         roof = {"bound": "hbm", "achieved": dw_alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": dw_alg_bytes}
@@ -324,35 +425,31 @@ def main():
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["peak_definition"] = ("HBM3E 8 TB/s" if roof["bound"] == "hbm" else
                                ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32-faithful product" if mfma_peak != FP32_MFMA_PEAK_TFLOPS else "FP32 MFMA peak"))
-    # every hot kernel by name (warm-up pass, all launch classes timed): ms per step, TFLOP/s, fraction of the FP32-MFMA peak
-    by_kernel = {}
+    # every hot kernel by name, from the per-kernel pass above
+    by_kernel = {"_source": "separate pass of the same %d iterations after the timed region, HIP events around every launch (%.4f ms/step wall with the events, "
+                            "the timed region has them around the dominant kernel only)" % (K, dt_all_events / K * 1e3)}
     for kname, cls in by_name.items():
-        ms = sum(tw[c][0] for c in cls); fl = sum(tw[c][2] for c in cls); nl = sum(tw[c][1] for c in cls)
-        if ms > 0 and W > 0:
-            by_kernel[kname] = {"ms_per_step": ms / W, "launches_per_step": nl / W, "tflops": (fl / ms / 1e9) if fl > 0 else None,
+        ms = sum(ta[c][0] for c in cls); nl = sum(ta[c][1] for c in cls)
+        fl = sum(ta[c][2] for c in cls) - masked_of(kname, cls)
+        if ms > 0:
+            by_kernel[kname] = {"ms_per_step": ms / K, "launches_per_step": nl / K, "tflops": (fl / ms / 1e9) if fl > 0 else None,
                                 "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None,
                                 "frac_of_bf16x6_peak": (fl / ms / 1e9 / BF16X6_PEAK_TFLOPS) if fl > 0 else None}
             if "dw" in cls:
-                if DW_BF and fl > 0:      # this kernel's own arithmetic: DW_PRODUCTS bf16 products per product
+                if DW_BF and fl > 0 and DW_PRODUCTS != 6:      # this kernel's own arithmetic: DW_PRODUCTS bf16 products per product
                     by_kernel[kname]["frac_of_bf16x%d_peak" % DW_PRODUCTS] = fl / ms / 1e9 / (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS)
-                    if DW_PRODUCTS != 6:
-                        by_kernel[kname].pop("frac_of_bf16x6_peak", None)
+                    by_kernel[kname].pop("frac_of_bf16x6_peak", None)
                 by_kernel[kname]["algorithmic_hbm_gbs"] = dw_alg_bytes / (ms / nl * 1e-3) / 1e9
                 by_kernel[kname]["frac_of_hbm_peak"] = by_kernel[kname]["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
+            if kname.startswith(("k_mlp", "k_dw")):
+                by_kernel[kname]["hbm_model_bytes_per_launch"] = hbm_model_bytes(kname, rows_mean, nl / K)
 
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of
-    # the same command (tools/collect_profiles.sh -> profiles/*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is
-    # quoted when it covers this kernel and workload, else null.
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of the same
+    # command (tools/collect_profiles.sh -> profiles/r*_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per launch) is quoted only when it
+    # covers this kernel and agrees with the byte model of THIS run's rows (hbm_model_bytes) - a stale file yields null.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
-    kname = dom
-    if os.path.exists(tpath) and not args.two_layer and (args.resx, args.resy, args.frames) == (768, 432, 80) and args.first_iter < 0:
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj["kernels"][kname]["hbm_bytes"]
-            traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " + tj["correction"] + ")"
-        except Exception:
-            traffic = None
+    if (args.resx, args.resy, args.frames) == (768, 432, 80) and not extra:
+        traffic, traffic_src = committed_traffic(dom, hbm_model_bytes(dom, rows_mean, n_launch / K))
 
     out = None
     if rank == 0:
@@ -364,7 +461,7 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (" + "; ".join(x for x in (
                 ("MLP chains bf16x6: operands split into 3 bf16, 6 partial products" + (" (EXPERIMENT: backward chain on 3 products)" if MLP_MODE == 2 else "")) if MLP_BF else "",
-                {1: "weight-gradient GEMM bf16x6", 2: "weight-gradient GEMM bf16x3: 2 bf16 per operand, 3 partial products, gradient error against fp64 held to 3x torch-fp32's at full size"}.get(DW_MODE, "")) if x)
+                {1: "weight-gradient GEMM bf16x6", 2: "NON-DEFAULT weight-gradient GEMM bf16x3: 2 bf16 per operand, 3 partial products, narrower than fp32"}.get(DW_MODE, "")) if x)
                 + "; fp32 accumulate)") if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
                                    "timed iterations %d..%d (global-rigidity rows while i <= 5000); %s"
@@ -379,10 +476,12 @@ def main():
                          "kernel_ms": dom_ms, "flops_per_launch": flops_launch, "launches_per_step": n_launch / K,
                          "by_kernel": by_kernel,
                          "valid_flow_fraction": float(nv.sum() / (2.0 * N * K)),
-                         "whole_step_tflops": V * total_flops / dt / 1e12, "whole_step_frac": V * total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "warmup_ms_per_step_by_kernel": {c: (tw[c][0] / max(tw[c][1], 1)) for c in classes},
-                         "warmup_tflops_by_kernel": {c: (tw[c][2] / tw[c][0] / 1e9 if tw[c][0] > 0 and tw[c][2] > 0 else None) for c in classes}},
+                         "whole_step_tflops": V * total_flops / dt / 1e12, "whole_step_frac": V * total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS},
         }
+        if dt3 is not None:     # extra keys, never `value`: the opt-in three-product weight-gradient GEMM on the same steps
+            out["value_bf16x3_dw"] = world * N * K / dt3
+            out["ms_per_step_bf16x3_dw"] = dt3 / K * 1e3
+            out["value_bf16x3_dw_note"] = "same K steps with af_set_dw_mode(h, 2): k_dw_bf<3>, 16-bit-mantissa operands, narrower than the reference's fp32 - not the headline"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.resx, args.resy, args.frames, 0, sds, video, args.cpu_seconds, args.two_layer)

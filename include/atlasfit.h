@@ -138,17 +138,19 @@ int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg);
 /* Read back n 64-byte pixel records of the packed table: out [n][16] = rgb(3), d/dx rgb(3), d/dy rgb(3), fwd flow(2),
  * bwd flow(2), fwd mask, bwd mask, fg mask, for pixel-frame indices inds[n] (the k of get_tuples' column k). */
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
-/* Arithmetic of the weight-gradient GEMMs (k_dw): 2 (default) = "bf16x3" — each fp32 operand split in registers into
- * two bf16 values (16 mantissa bits), three partial products accumulated in fp32 on the bf16 matrix pipe; shipped
- * under the rule that the gradient error against an fp64 twin stays within 3x of torch-fp32's own at full size
- * (tests/test_gpu_fullsize.py).  1 = fp32-faithful "bf16x6" (three bf16 values per operand, the six leading partial
- * products: tests/test_split_precision.py); 0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  The three are held
- * against each other in tests/test_gpu_dw_modes.py.  Env AF_DW_MODE=<m> at af_create; AF_DW_FP32=1 selects 0. */
+/* Arithmetic of the weight-gradient GEMMs (k_dw), for the loop AND for pre_train_mapping's dW: 1 (default) = fp32-faithful
+ * "bf16x6" — each fp32 operand split in registers into three bf16 values, the six leading partial products accumulated in
+ * fp32 on the bf16 matrix pipe (dropped terms <= 2^-24 relative: tests/test_split_precision.py).  2 (opt-in) = "bf16x3" —
+ * two bf16 values per operand (16 mantissa bits), three partial products: NARROWER than the reference's fp32, faster,
+ * measured within 3x of torch-fp32's own gradient error against an fp64 twin at full size (tests/test_gpu_fullsize.py);
+ * never the default and never bench.py's headline value.  0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  The three
+ * are held against each other in tests/test_gpu_dw_modes.py.  Env AF_DW_MODE=<m> at af_create; AF_DW_FP32=1 selects 0.
+ * A switch re-cuts all split-K schedules (their tile costs belong to the arithmetic). */
 int af_set_dw_mode(af_handle* h, int mode);
 /* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
  * = bf16x6, 0 = fp32 matrix pipe, 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16
  * operands — a measured experiment, not a default.  Env AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.
- * pre_train_mapping always runs the fp32 16-row chains. */
+ * pre_train_mapping's MLP chains always run the fp32 16-row kernels (mlp16.hip); its weight-gradient GEMM follows af_set_dw_mode. */
 int af_set_mlp_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);

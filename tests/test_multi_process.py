@@ -89,3 +89,21 @@ def test_multi_video_launcher_shards_and_gathers():
     assert out1 is None and out0["videos"] == 5 and out0["n_gpus"] == 2
     assert out0["psnr"] == {"a": 21.0, "bb": 22.0, "ccc": 23.0, "dddd": 24.0, "eeeee": 25.0}
     assert out0["wall_s"] >= 0.19                    # rank 1: two videos at 0.1 s each
+
+
+def test_bare_bench_invocation_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no RANK in the environment (how the driver calls it) must not die on
+    an assertion: it re-execs itself under torch.distributed.run, both ranks reach init_process_group, the barrier-bracketed
+    region and its MAX all-reduce.  AF_BENCH_DRY_RUN=gloo stops short of the GPU so this runs on CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AF_BENCH_DRY_RUN"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                   # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["video_of_rank0"] == [0]
+    assert out["max_region_s"] >= 0.02                 # rank 1 sleeps 20 ms: every rank reports the MAX
