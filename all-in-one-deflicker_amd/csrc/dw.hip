@@ -19,6 +19,7 @@
 // LDS fragment read and every LDS-DMA issue sits behind its own MFMA (sched_group_barrier), never in a burst.
 // MFMA: A[m = out feature][k = row], B[k = row][n = in feature]; four consecutive k of one lane half are
 // one ds_read_b128.  db falls out of the A fragments for free.
+#include <utility>
 #include "af_dev.h"
 
 #ifndef DW_ABL
@@ -28,6 +29,9 @@
 #define DW_STAGES 4
 #endif
 #define DW_LDS (DW_STAGES * 32768)
+#ifndef DW_PIPE
+#define DW_PIPE 1    // software-pipelined operand split in k_dw_bf (0: the round-2 stage, kept for A/B timing in tools/dwbench.hip)
+#endif
 
 template <int N> AF_DEV void dw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // s_barrier without the release/acquire fences of __syncthreads(): a fence makes hipcc drain vmcnt to 0 in front of the
@@ -171,6 +175,15 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 // ds_read_b128 of the T-layout half tile per operand tile.
 #include "bfsplit.h"
 
+// NM MFMAs, each followed by its share of NV VALU instructions, at most one LDS read and one VMEM instruction
+template <int NM, int NV, int... I>
+AF_DEV void dw_sgb_spread(std::integer_sequence<int, I...>) {
+  ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0),
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV * (I + 1)) / NM - (NV * I) / NM, 0),
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0),
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)), ...);
+}
+
 template <int TO, int TI, int TOW, int TIW, int NPROD = 6>
 AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
                           int a0, int b0, bool store_w, bool store_db) {
@@ -223,6 +236,86 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
   const int sw = (m >> 2) & 3;
   const int off0 = m * 64 + (((2 * h) ^ sw) << 4), off1 = m * 64 + (((2 * h + 1) ^ sw) << 4);     // rows 8h..8h+3, 8h+4..8h+7
   const int abase = a0 * 2048, bbase = A_B + b0 * 2048;
+#if DW_PIPE
+  // Software-pipelined stage: every VALU instruction of the operand split sits in the shadow of an MFMA (one wave per SIMD
+  // issues in order: a clump of VALU in front of the products is time the matrix pipe idles).  Entering stage s a wave holds
+  // the SPLIT A operands of the stage (sa, produced during stage s-1), the raw B fragments of the stage (rb) and the split
+  // of B column 0 (sb).  The stage publishes stage s+1 (counted wait + barrier), reads its raw A fragments and issues the
+  // DMA of stage s+3, then runs column by column: behind the NPROD x TOW products of column y go the split of B column y+1
+  // (column 0 of stage s+1 for the last), the split of A fragment y of stage s+1 (all of them spread over the columns when
+  // TOW != TIW) and the refresh of column y's raw registers for stage s+1.
+  f32x4 ran[TOW][2];                                     // raw A fragments of the NEXT stage
+  f32x4 rb[TIW][2];                                      // raw B fragments: column y is refreshed for the next stage while column y runs
+  DwSplit sa[2][TOW];                                    // split A operands: [cur] this stage, [cur ^ 1] the next (filled during this one)
+  DwSplit sb;
+  auto read_an = [&](const char* slot) {
+#pragma unroll
+    for (int x = 0; x < TOW; ++x) { ran[x][0] = *(const f32x4*)(slot + abase + x * 2048 + off0); ran[x][1] = *(const f32x4*)(slot + abase + x * 2048 + off1); }
+  };
+  auto read_b = [&](int y, const char* slot) {
+    rb[y][0] = *(const f32x4*)(slot + bbase + y * 2048 + off0); rb[y][1] = *(const f32x4*)(slot + bbase + y * 2048 + off1);
+  };
+  auto split_a = [&](int buf, int x, bool real) {      // real == false: the stage behind the last one (a re-staged copy): its rows must not reach db
+    sa[buf][x] = dw_split8<LV>(ran[x][0], ran[x][1]);
+    const f32x4 t = ran[x][0] + ran[x][1];
+    const float rs = (t[0] + t[1]) + (t[2] + t[3]);
+    dbacc[x] += real ? rs : 0.f;
+  };
+  constexpr int APC = (TOW + TIW - 1) / TIW;             // A fragments split per column
+  auto stage = [&](int s, int cur) {
+    const char* nslot = smem + ((s + 1) % DW_STAGES) * SLOT;      // past the last stage: harmless reads of a re-staged slot
+    dw_wait_vm<(DW_STAGES - 3) * NI>();                  // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_barrier();                                        // ... for every wave; every wave holds what it needs of stage s-1
+    read_an(nslot);
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue(s + DW_STAGES - 1, k);      // into the slot stage s-1 left
+#pragma unroll
+    for (int y = 0; y < TIW; ++y) {
+      DwSplit sbn;
+      read_b(y, nslot);                                  // column y of stage s was split one column ago: its registers take stage s+1
+      if (y + 1 < TIW) sbn = dw_split8<LV>(rb[y + 1][0], rb[y + 1][1]);
+#pragma unroll
+      for (int i = 0; i < APC; ++i) if (y * APC + i < TOW) split_a(cur ^ 1, y * APC + i, s + 1 < S);
+      if (y + 1 == TIW) sbn = dw_split8<LV>(rb[0][0], rb[0][1]);      // stage s+1's column 0 (read behind column 0 of this stage)
+      if constexpr (!(DW_ABL & 2)) {
+        if constexpr (NPROD == 6) {
+#pragma unroll
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].h, sb.l, acc[x][y]);
+#pragma unroll
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].l, sb.h, acc[x][y]);
+#pragma unroll
+          for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].m, sb.m, acc[x][y]);
+        }
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].h, sb.m, acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].m, sb.h, acc[x][y]);
+      }
+#pragma unroll
+      for (int x = 0; x < TOW; ++x) acc[x][y] = dw_mfma_bf(sa[cur][x].h, sb.h, acc[x][y]);
+      if constexpr (!(DW_ABL & 4)) {
+        // per MFMA: itself, then its share of the column's VALU (split of one B column + APC A fragments, ~45 each at three levels),
+        // at most one LDS read and one DMA issue
+        constexpr int NM = NPROD * TOW, NV = (LV == 3 ? 46 : 28) * (1 + APC);
+        dw_sgb_spread<NM, NV>(std::make_integer_sequence<int, NM>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sb = sbn;
+    }
+  };
+  dw_wait_vm<(DW_STAGES - 2) * NI>();                                    // stage 0 has landed
+  dw_barrier();
+  read_an(smem);
+#pragma unroll
+  for (int y = 0; y < TIW; ++y) read_b(y, smem);
+#pragma unroll
+  for (int x = 0; x < TOW; ++x) split_a(0, x, true);
+  sb = dw_split8<LV>(rb[0][0], rb[0][1]);
+  for (int s = 0; s < S; s += 2) {                       // S is even (two stages per 32-row tile): no register copies between stages
+    stage(s, 0);
+    stage(s + 1, 1);
+  }
+#else
   f32x4 ra[2][TOW][2];                                   // raw A fragments, double-buffered across stages
   f32x4 rb[TIW][2];                                      // raw B fragments: column y is refreshed for the next stage while column y runs
   auto read_a = [&](int buf, const char* slot) {
@@ -294,6 +387,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     stage(s, 0);
     stage(s + 1, 1);
   }
+#endif
   dw_wait_vm<0>();
   dw_barrier();
 

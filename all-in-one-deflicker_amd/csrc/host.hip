@@ -306,7 +306,7 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   // narrow shapes (layer 0, skip columns, output layer) are bound by the latency of their 36-40 KB operand tiles, so they do not
   // get cheaper when the 8x8 tiles move to the bf16 matrix pipe:
   //   fp32 MFMA k_dw:  8x8 7.9 us/tile, 8x2 2.4, 8x1 1.6, 1x8 1.6, 1x2 1.2      bf16x6 k_dw_bf:  8x8 5.47, 8x2 2.0, 8x1 1.44, 1x8 1.44, 1x2 0.9
-  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 126.0, 91.0, 91.0, 56.0}, {306.0, 150.0, 132.0, 135.0, 78.0}};
+  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 133.0, 113.0, 108.0, 72.0}, {306.0, 168.0, 157.0, 150.0, 95.0}};     // rows 1, 2 re-fitted in round 3 for the software-pipelined k_dw_bf (gpurun_out/r3g_dwfit_m*.txt)
   const double seg_cost = 60.0;
   auto tile_cost = [&](int j) { return kTileCost[h->dw_mode][sc.jobs[j].shape]; };
   double work = 0;

@@ -191,6 +191,6 @@ AF_DEV void store_tile_part(const float (&v)[128], __amdgpu_buffer_rsrc_t r, int
 // hardware bounds check, so the store sites need no branch.
 struct TileStore {
   __amdgpu_buffer_rsrc_t r; int voff;
-  template <int G> AF_DEV void part(const float (&v)[128]) { if constexpr (G < 8 && !(AF_ABL & 1)) store_tile_part<G>(v, r, voff); }
+  template <int G> AF_DEV void part(const float (&v)[128]) const { if constexpr (G < 8 && !(AF_ABL & 1)) store_tile_part<G>(v, r, voff); }
 };
 

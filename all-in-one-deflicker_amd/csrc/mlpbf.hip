@@ -50,10 +50,17 @@ struct BfStream {
     if constexpr (!(AF_ABL & 2)) af_glds16(src + k * 4096, p_dst + k * 4096);
     ++p_it;
   }
+  // the five pieces a k-step issues right behind its own publish (group 3 of an odd k-step), for a stage opened elsewhere
+  AF_DEV void lead5() { issue1(); issue1(); issue1(); issue1(); issue1(); }
   AF_DEV void start(const void* img, int tid, int wave_) { src = (const char*)img + tid * 16; wave = wave_; stg = 0; begin_stage(); }
+  // KEEP: vector-memory instructions (tile stores) this wave has issued AFTER the last piece of the chunk being published — they
+  // may stay in flight.  vmcnt counts loads and stores alike and retires them in issue order, so a counted wait covers every DMA
+  // piece of the chunk without draining the youngest stores (a vmcnt(0) here waits for the write acknowledgement of stores
+  // issued a few cycles earlier: ~10 % of a training chain).  Callers that cannot bound the count pass 0.
+  template <int KEEP = 0>
   AF_DEV const char* publish(int BYTES) {
-    while (p_it < NI) issue1();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (KEEP == 0) { while (p_it < NI) issue1(); }      // (with stores behind the DMA the top-up would break the count: those callers issue all NI pieces themselves)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KEEP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char* cur = smem + (stg & 1) * AF_SLOT_BF;
@@ -69,6 +76,18 @@ AF_DEV f32x4 bf_frag(const char* lane_base, int sl, int T, int lvl) {
   if constexpr (AF_ABL & 8) return f32x4{(float)sl, (float)T, (float)lvl, 1.f};
   return *(const f32x4*)(lane_base + ((sl * 8 + T) * 3 + lvl) * 1024);
 }
+// The six-product k-step reads its fragments straight into accumulator registers: the 96 registers of three fragment sets do not
+// fit beside the 128 activation registers in the VGPR half, and a compiler-visible load lands in a VGPR first (measured: the
+// slotted k-step then spills inside the split units).  The read is invisible to hipcc's waitcnt insertion - every consumer slot
+// group starts with bf_lds_wait() (all fragment reads are issued at least four MFMAs before their first use).
+template <int SL, int T, int LVL>
+AF_DEV f32x4 bf_frag_a(uint32_t lane_addr) {
+  f32x4 v;
+  if constexpr (AF_ABL & 8) { v = f32x4{(float)SL, (float)T, (float)LVL, 1.f}; asm volatile("" : "+a"(v)); return v; }
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(lane_addr), "n"(((SL * 8 + T) * 3 + LVL) * 1024));
+  return v;
+}
+AF_DEV void bf_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 AF_DEV f32x16 bf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -94,7 +113,11 @@ template <int N> AF_DEV void bf_sgb() {
 // behind the whole block, used by k-step 15) and fetches the lo-level fragments of that chunk's first k-step — inside a
 // block only: across layers nothing is carried (bf_enter), so that every layer of the runtime loop runs the same code.
 // NPROD = 3 (backward chain only, af_set_mlp_mode(h, 2); an experiment, not the default): hi + mid operands, three products.
-template <int S, bool ZI, int NPROD, class Hook>
+// NST: vector-memory instructions store_hook issues in a k-step S < 8 (16 tile stores, or 0 for a hook that stores nothing).
+// DMA pieces of the chunk behind the current one: 5 right after its stage opens (group 3 of the odd k-step), 3 + 4 in groups
+// 1 and 3 of the even k-step, none in the odd k-step's first two groups — all twelve are at least 24 MFMAs old at the publish,
+// and only the odd k-step's own stores are younger (the publish's counted wait leaves exactly those in flight).
+template <int S, bool ZI, int NPROD, int NST, class Hook>
 AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& store_hook) {
   constexpr bool NEXT_BF = S != 15;
   constexpr int sl = S & 1;
@@ -116,7 +139,7 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
       }
     }
   }
-  cs.issue1();
+  if constexpr (!last_in_chunk) { cs.issue1(); cs.issue1(); cs.issue1(); }
   if constexpr (!X3) bf_sgb<8>();
   // ---- group 2: W_mid x (B_mid, B_hi) (16 MFMAs); fetch W_hi; the deferred tile stores of this k-step's feature tile
 #pragma unroll
@@ -134,12 +157,11 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
       acc[T] = bf_mfma(fm[T], pp.b.h, acc[T]);
     }
   }
-  cs.issue1(); cs.issue1();
   store_hook(GIdx<S>{});
   bf_sgb<X3 ? 8 : 16>();
   // ---- publish the next chunk (odd k-steps): every read of this chunk has been issued; the slot can be refilled
   const char* nxt_lane = lane_base;
-  if constexpr (last_in_chunk) nxt_lane = cs.publish(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
+  if constexpr (last_in_chunk) nxt_lane = cs.template publish<(S < 8 ? NST : 0)>(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
   // ---- group 3: W_hi x (B_lo, B_mid, B_hi) (24 MFMAs); fetch the next k-step's W_lo and split its B operand
   DwSplit bn = pp.b;
   f32x4 fln[8];
@@ -160,8 +182,110 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
   for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.m, acc[T]);
 #pragma unroll
   for (int T = 0; T < 8; ++T) acc[T] = bf_mfma(fh[T], pp.b.h, acc[T]);
-  cs.issue1(); cs.issue1(); cs.issue1();
+  cs.issue1(); cs.issue1(); cs.issue1(); cs.issue1();
+  if constexpr (last_in_chunk) cs.issue1();
   bf_sgb<X3 ? 16 : 24>();
+#pragma unroll
+  for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
+  pp.b = bn;
+  lane_base = nxt_lane;
+}
+
+
+// ---- the six-product k-step as 48 hand-placed issue slots --------------------------------------------------------------------
+// One wave per SIMD issues in order: an MFMA holds the matrix pipe for 32 cycles, and whatever issues behind it within those
+// cycles is free — up to ~5 light instructions (VALU, ds_read) or ONE vector-memory instruction (tools/issueprobe_gen.py: the
+// whole k-step mix of 24 fragment reads, 44 split VALU, 6 DMA pieces and 16 stores costs 1572 ticks hand-placed, the same as 48
+// bare MFMAs).  hipcc's scheduler does not produce such a stream from sched_group_barrier hints (stores and DMA pieces come out in
+// clumps of 5-16, fragment reads land behind the LAST MFMAs of a group so that the next group's first use exposes the LDS latency),
+// so the k-step is written slot by slot, every slot fenced by sched_barrier(0): slot I = MFMA I + the fillers listed below.
+//   MFMAs    0-7 W_lo x B_hi | 8-15 W_mid x B_mid, 16-23 W_mid x B_hi | [publish, odd k-steps] | 24-31 W_hi x B_lo, 32-39 x B_mid, 40-47 x B_hi
+//   reads    W_mid fragments two per slot in 0-3, W_hi in 8-11, the next k-step's W_lo in 24-27 (each a whole group ahead of its use)
+//   DMA      even k-step: slots 4-6 and 32-35; odd: 28-32 (the five pieces that open the stage behind the publish)
+//   stores   (k-steps 0-7 of a training chain, 16 per k-step) even: 12-23, 28-31; odd: 4-7, 12-23 — on an odd k-step all sixteen are
+//            younger than the last DMA piece (even slot 35): exactly the KEEP the publish's counted vmcnt leaves in flight
+//   split    of the next k-step's B operand in twelve units of 3-4 VALU: even 7, 36-46; odd 33-44
+struct BfSplitState { f32x4 ra, rb; };       // residuals between the three units of a pair (vectors: constant-index lanes stay in registers)
+template <int U, int S8>
+AF_DEV void bf_split_unit(const float (&in)[128], DwSplit& bn, BfSplitState& st) {
+  constexpr int i = U / 3, ph = U % 3;
+  if constexpr (DW_ABL & 1) { if constexpr (ph == 0) { bn.h[i] = __builtin_bit_cast(uint32_t, in[S8 + 2 * i]); bn.m[i] = bn.h[i]; bn.l[i] = bn.h[i]; } return; }
+  // the empty volatile asm at the end of a unit ties its results to this slot: pure VALU code has no place of its own in the
+  // instruction selector's order and would otherwise be emitted next to its last use, i.e. all 44 in one clump behind slot 47
+  if constexpr (ph == 0) {
+    const float a = in[S8 + 2 * i], b = in[S8 + 2 * i + 1];
+    uint32_t h = dw_pk(a, b);
+    float ra = dw_sub(a, __builtin_bit_cast(float, h << 16)), rb = dw_sub(b, __builtin_bit_cast(float, h & 0xffff0000u));
+    asm volatile("" : "+v"(h), "+v"(ra), "+v"(rb));
+    bn.h[i] = h; st.ra[i] = ra; st.rb[i] = rb;
+  } else if constexpr (ph == 1) {
+    uint32_t m = dw_pk(st.ra[i], st.rb[i]);
+    float ra = dw_sub(st.ra[i], __builtin_bit_cast(float, m << 16)), rb = dw_sub(st.rb[i], __builtin_bit_cast(float, m & 0xffff0000u));
+    asm volatile("" : "+v"(m), "+v"(ra), "+v"(rb));
+    bn.m[i] = m; st.ra[i] = ra; st.rb[i] = rb;
+  } else {
+    uint32_t l = dw_pk(st.ra[i], st.rb[i]);
+    asm volatile("" : "+v"(l));
+    bn.l[i] = l;
+  }
+}
+template <int S, bool ZI, int NST, int I>
+AF_DEV void bf_slot(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, f32x4 (&fm)[8], f32x4 (&fh)[8], f32x4 (&fln)[8], DwSplit& bn, BfSplitState& st,
+                    uint32_t la, uint32_t nla, BfStream& cs, const TileStore& ts) {
+  constexpr int sl = S & 1, T = I & 7;
+  constexpr bool odd = sl == 1, NEXT_BF = S != 15, stores = NST > 0 && S < 8;
+  if constexpr (I == 0 || I == 8 || I == 24) bf_lds_wait();          // the fragments of this slot group have landed (read >= 4 MFMAs ago)
+  // ---- the MFMA
+  if constexpr (I < 8) {
+    pin_acc(pp.fl[T]);
+    if constexpr (ZI && S == 0) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[T] = bf_mfma(pp.fl[T], pp.b.h, z);
+    } else {
+      acc[T] = bf_mfma(pp.fl[T], pp.b.h, acc[T]);
+    }
+  } else if constexpr (I < 16) { pin_acc(fm[T]); acc[T] = bf_mfma(fm[T], pp.b.m, acc[T]); }
+  else if constexpr (I < 24) acc[T] = bf_mfma(fm[T], pp.b.h, acc[T]);
+  else if constexpr (I < 32) { pin_acc(fh[T]); acc[T] = bf_mfma(fh[T], pp.b.l, acc[T]); }
+  else if constexpr (I < 40) acc[T] = bf_mfma(fh[T], pp.b.m, acc[T]);
+  else acc[T] = bf_mfma(fh[T], pp.b.h, acc[T]);
+  // ---- fragment reads, a whole group ahead of their first use
+  if constexpr (I < 4) { fm[2 * I] = bf_frag_a<sl, 2 * I, 1>(la); fm[2 * I + 1] = bf_frag_a<sl, 2 * I + 1, 1>(la); }
+  if constexpr (I >= 8 && I < 12) { fh[2 * (I - 8)] = bf_frag_a<sl, 2 * (I - 8), 0>(la); fh[2 * (I - 8) + 1] = bf_frag_a<sl, 2 * (I - 8) + 1, 0>(la); }
+  if constexpr (I >= 24 && I < 28) {
+    constexpr int t0 = 2 * (I - 24);
+    if constexpr (!odd)         { fln[t0] = bf_frag_a<1, t0, 2>(la); fln[t0 + 1] = bf_frag_a<1, t0 + 1, 2>(la); }
+    else if constexpr (NEXT_BF) { fln[t0] = bf_frag_a<0, t0, 2>(nla); fln[t0 + 1] = bf_frag_a<0, t0 + 1, 2>(nla); }
+    else                        { fln[t0] = pp.fl[t0]; fln[t0 + 1] = pp.fl[t0 + 1]; }
+  }
+  // ---- LDS-DMA pieces of the chunk behind the published one
+  if constexpr ((!odd && ((I >= 4 && I < 7) || (I >= 32 && I < 36))) || (odd && I >= 28 && I < 33)) cs.issue1();
+  // ---- tile stores of feature tile S (k-steps 0..7)
+  if constexpr (stores) {
+    constexpr int rr = !odd ? (I >= 12 && I < 24 ? I - 12 : (I >= 28 && I < 32 ? 12 + I - 28 : -1))
+                            : (I >= 4 && I < 8 ? I - 4 : (I >= 12 && I < 24 ? 4 + I - 12 : -1));
+    if constexpr (rr >= 0) af_bs32(in[(S & 7) * 16 + rr], ts.r, ts.voff + (rr & 3) * 128, (32 * (S & 7) + 8 * (rr >> 2)) * 128);
+  }
+  // ---- split of the next k-step's B operand
+  if constexpr (S + 1 < 16) {
+    constexpr int u = !odd ? (I == 7 ? 0 : (I >= 36 && I < 47 ? 1 + I - 36 : -1)) : (I >= 33 && I < 45 ? I - 33 : -1);
+    if constexpr (u >= 0) bf_split_unit<u, 8 * (S + 1)>(in, bn, st);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int S, bool ZI, int NST, int... I0, int... I1>
+AF_DEV void bf_kstep6(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, const TileStore& ts,
+                      std::integer_sequence<int, I0...>, std::integer_sequence<int, I1...>) {
+  f32x4 fm[8], fh[8], fln[8];
+  DwSplit bn = pp.b;
+  BfSplitState st{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const char* nxt_lane = lane_base;
+  __builtin_amdgcn_sched_barrier(0);
+  const uint32_t la = (uint32_t)(size_t)lane_base;
+  (bf_slot<S, ZI, NST, I0>(acc, in, pp, fm, fh, fln, bn, st, la, la, cs, ts), ...);                              // slots 0..23
+  if constexpr ((S & 1) == 1) nxt_lane = cs.template publish<(S < 8 ? NST : 0)>(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
+  const uint32_t nla = (uint32_t)(size_t)nxt_lane;
+  (bf_slot<S, ZI, NST, 24 + I1>(acc, in, pp, fm, fh, fln, bn, st, la, nla, cs, ts), ...);                        // slots 24..47
 #pragma unroll
   for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
   pp.b = bn;
@@ -170,18 +294,24 @@ AF_DEV void bf_kstep(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const
 
 // A whole 256 -> 256 product (16 k-steps = 8 chunks).  On entry the first chunk is published at lane_base (bf_enter has
 // fetched its first fragments); on exit lane_base addresses the published chunk behind the block (after_bytes long).
-template <bool ZI, int NPROD, class Hook, int... Ss>
-AF_DEV void bf_block_impl(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook& hook, std::integer_sequence<int, Ss...>) {
-  (bf_kstep<Ss, ZI, NPROD>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook), ...);
+template <bool ZI, int NPROD, int NST, int... Ss>
+AF_DEV void bf_block_impl(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, const TileStore& ts, std::integer_sequence<int, Ss...>) {
+  if constexpr (NPROD == 6) {
+    (bf_kstep6<Ss, ZI, NST>(acc, in, pp, lane_base, cs, lane_off, after_bytes, ts, std::make_integer_sequence<int, 24>{}, std::make_integer_sequence<int, 24>{}), ...);
+  } else {
+    auto hook = [&](auto gi) { if constexpr (NST > 0) ts.template part<decltype(gi)::value>(in); };
+    (bf_kstep<Ss, ZI, NPROD, NST>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook), ...);
+  }
 }
-template <bool ZI, int NPROD = 6, class Hook>
-AF_DEV void bf_block(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, Hook&& hook) {
-  bf_block_impl<ZI, NPROD>(acc, in, pp, lane_base, cs, lane_off, after_bytes, hook, std::make_integer_sequence<int, 16>{});
+// NST: 16 when the chain stores its tiles (training forward, backward), 0 otherwise (ts is then unused)
+template <bool ZI, int NPROD, int NST>
+AF_DEV void bf_block(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, const char*& lane_base, BfStream& cs, int lane_off, int after_bytes, const TileStore& ts) {
+  bf_block_impl<ZI, NPROD, NST>(acc, in, pp, lane_base, cs, lane_off, after_bytes, ts, std::make_integer_sequence<int, 16>{});
 }
 // entering a block: the lo-level fragments and the split B operand of its first k-step
 AF_DEV void bf_enter(BfPipe& pp, const float (&in)[128], const char* lane_base) {
 #pragma unroll
-  for (int T = 0; T < 8; ++T) pp.fl[T] = bf_frag(lane_base, 0, T, 2);
+  for (int T = 0; T < 8; ++T) pp.fl[T] = bf_frag(lane_base, 0, T, 2);     // compiler-visible reads: both k-step flavours may follow
   pp.b = bf_split_in(in, 0);
 }
 
@@ -286,6 +416,7 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
   mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
   relu_out(0);
   const char* lane_base = cs.publish(CB::HID) + lane_off;
+  cs.lead5();
 
   // ---- hidden layers 1 .. NL-2: eight bf16 chunks each (+ the fp32 block of the skip columns); every iteration runs the
   // same code — what lies behind a layer (its skip block, the next layer's first chunk, the output layer) is only a size
@@ -295,11 +426,12 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
     bf_enter(pp, in, lane_base);
     const bool skip = NS::SKIP != 0 && ((NS::SKIP >> l) & 1);
     const int behind = l == NS::NL - 2 ? CB::LAST : CB::HID;
-    bf_block<false>(acc, in, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, hook_store);
+    bf_block<false, 6, ((TRAIN && !(AF_ABL & 1)) ? 16 : 0)>(acc, in, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, ts);
     if constexpr (NS::SKIP != 0) {
       if (skip) {
         mm_block<8, NS::PEG, 0, 4>(acc, pe, lane_base - lane_off + a_off8, hook_dma);
         lane_base = cs.publish(behind) + lane_off;
+        cs.lead5();
       }
     }
     relu_out(l);
@@ -408,12 +540,13 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
   mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
   mask_out(NS::NL - 1);
   const char* lane_base = cs.publish(CB::HID) + lane_off;
+  cs.lead5();
 
 #pragma unroll 1
   for (int l = NS::NL - 2; l >= 1; --l) {
     bf_enter(pp, in, lane_base);
     // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
-    bf_block<true, NPROD>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), hook_store);
+    bf_block<true, NPROD, ((AF_ABL & 1) ? 0 : 16)>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), ts);
     mask_out(l);
   }
   lane_base -= lane_off;
