@@ -57,6 +57,7 @@ struct FwdArgs {
   int nt_stride;              // row tiles per layer plane of acts / masks (the whole batch)
   const int* live_rows;       // null, or: rows [live_base + *live_rows, NT*32) do not exist this iteration (compacted flow matches,
   int live_base;              // written by k_prep); workgroups wholly beyond the last live row tile return at once
+  int nl;                     // layers of this net (2..AF_MAX_LAYERS; number_of_layers_* of the config): the layer loops are runtime loops
 };
 
 struct BwdArgs {
@@ -75,6 +76,7 @@ struct BwdArgs {
   int NT;
   int nt_stride;
   const int* live_rows; int live_base;      // as in FwdArgs
+  int nl;                     // layers of this net
 };
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip

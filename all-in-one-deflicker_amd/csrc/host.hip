@@ -23,11 +23,11 @@ int af_mlp_init();
 int af_launch_fwd16(int net, const FwdArgs* a, hipStream_t s);
 int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s);
 int af_mlp16_init();
-int af_mlp_chunk_bytes(int net, int which);
+int af_mlp_chunk_bytes(int net, int which, int nl);
 int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s);
 int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s);
 int af_mlp_bf_init();
-int af_mlp_chunk_bytes_bf(int net, int which);
+int af_mlp_chunk_bytes_bf(int net, int which, int nl);
 int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s);
 int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
@@ -113,6 +113,7 @@ struct af_handle {
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0;
+  double flop_fwd[AF_MAX_NETS] = {0}, flop_dx[AF_MAX_NETS] = {0};     // algorithmic FLOPs per MLP row of each net as built (forward == dW; dX chain), BASELINE.md 3
   int dw_mode = 1;                            // k_dw arithmetic (dw.hip): 1 = bf16x6 (fp32-faithful, the default), 2 = bf16x3 (hi + mid bf16 per operand, three products; opt-in), 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
@@ -133,8 +134,8 @@ namespace {
 // timing classes (include/atlasfit.h: af_get_timing): the two forward and the two backward launches of a step
 enum { T_PREP = 0, T_FWD_1 = 1, T_FWD_2 = 2, T_LOSS = 3, T_BWD_1 = 4, T_BWD_2 = 5, T_DW = 6, T_ADAM = 7 };
 // algorithmic FLOPs per MLP row (BASELINE.md §3 / SURVEY.md §8d), indexed by af_net: forward (== dW) and dX chain
-const double kFlopFwd[AF_MAX_NETS] = {526848.0, 829168.0, 264704.0, 802304.0};
-const double kFlopDx[AF_MAX_NETS]  = {525312.0, 808448.0, 263168.0, 786944.0};
+// (the shipped architecture: forward 526848 / 829168 / 264704 / 802304, dX chain 525312 / 808448 / 263168 / 786944; af_create
+// computes them for the configured layer counts: forward = 2 sum_l in_l out_l, dX = 2 (sum_{l>=1} 256 out_l + [atlas] in_0 256))
 
 template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
@@ -196,8 +197,8 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
 // per 256x256 hidden product, in consumption order (mlpbf.hip).  Returns false if the sizes disagree with the kernels'.
 bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
   const int peg = (n.pe_feats + 7) / 8;
-  const int cb_l0 = af_mlp_chunk_bytes_bf(n.id, 0), cb_hid = af_mlp_chunk_bytes_bf(n.id, 1), cb_skip = af_mlp_chunk_bytes_bf(n.id, 2);
-  const int cb_last = af_mlp_chunk_bytes_bf(n.id, 3), cb_blast = af_mlp_chunk_bytes_bf(n.id, 4), cb_bl0h = af_mlp_chunk_bytes_bf(n.id, 5);
+  const int cb_l0 = af_mlp_chunk_bytes_bf(n.id, 0, n.NL), cb_hid = af_mlp_chunk_bytes_bf(n.id, 1, n.NL), cb_skip = af_mlp_chunk_bytes_bf(n.id, 2, n.NL);
+  const int cb_last = af_mlp_chunk_bytes_bf(n.id, 3, n.NL), cb_blast = af_mlp_chunk_bytes_bf(n.id, 4, n.NL), cb_bl0h = af_mlp_chunk_bytes_bf(n.id, 5, n.NL);
   for (int l = 0; l < AF_MAX_LAYERS; ++l) n.sf_hid[l] = n.sf_fp[l] = n.sb_hid[l] = n.sb_fp[l] = -1;
   n.sf_base = f_cursor; n.sb_base = b_cursor;
   size_t off = 0;
@@ -221,12 +222,12 @@ bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
 // be exactly that sequence, contiguous.
 bool check_chunk_plan(const NetDesc& n) {
   std::vector<int> f, b;
-  f.push_back(af_mlp_chunk_bytes(n.id, 0));
-  for (int l = 1; l < n.NL - 1; ++l) { for (int c = 0; c < 4; ++c) f.push_back(af_mlp_chunk_bytes(n.id, 1)); if ((n.skip >> l) & 1) f.push_back(af_mlp_chunk_bytes(n.id, 2)); }
-  f.push_back(af_mlp_chunk_bytes(n.id, 3));
-  b.push_back(af_mlp_chunk_bytes(n.id, 4));
-  for (int l = n.NL - 2; l >= 1; --l) for (int c = 0; c < 4; ++c) b.push_back(af_mlp_chunk_bytes(n.id, 1));
-  if (n.dx0) b.push_back(af_mlp_chunk_bytes(n.id, 5));
+  f.push_back(af_mlp_chunk_bytes(n.id, 0, n.NL));
+  for (int l = 1; l < n.NL - 1; ++l) { for (int c = 0; c < 4; ++c) f.push_back(af_mlp_chunk_bytes(n.id, 1, n.NL)); if ((n.skip >> l) & 1) f.push_back(af_mlp_chunk_bytes(n.id, 2, n.NL)); }
+  f.push_back(af_mlp_chunk_bytes(n.id, 3, n.NL));
+  b.push_back(af_mlp_chunk_bytes(n.id, 4, n.NL));
+  for (int l = n.NL - 2; l >= 1; --l) for (int c = 0; c < 4; ++c) b.push_back(af_mlp_chunk_bytes(n.id, 1, n.NL));
+  if (n.dx0) b.push_back(af_mlp_chunk_bytes(n.id, 5, n.NL));
   auto same = [](const std::vector<AfChunk>& plan, const std::vector<int>& want) {
     if (plan.size() != want.size()) return false;
     uint32_t off = 0;
@@ -428,7 +429,7 @@ FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, 
   a.wimg = bf ? (const float*)(h->img_sf + n.sf_base) : h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
   a.in = in; a.in1 = nullptr; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
-  a.NT = NT; a.nt_stride = NT;
+  a.NT = NT; a.nt_stride = NT; a.nl = n.NL;
   return a;
 }
 
@@ -436,7 +437,7 @@ BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT, bool bf) {
   BwdArgs a{};
   a.wimg = bf ? (const float*)(h->img_sb + n.sb_base) : h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
   a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
-  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT;
+  a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT; a.nl = n.NL;
   return a;
 }
 
@@ -491,7 +492,7 @@ int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool
   for (const FwdPart& p : parts) {
     if (p.a.NT <= p.a.tile0) continue;
     m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
-    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * kFlopFwd[p.net];
+    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_fwd[p.net];
   }
   if (m.n == 0) return 0;
   Timer t(h, cls, fl);
@@ -504,7 +505,7 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   for (const BwdPart& p : parts) {
     if (p.a.NT <= p.a.tile0) continue;
     m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
-    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * kFlopDx[p.net];
+    fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_dx[p.net];
   }
   if (m.n == 0) return 0;
   Timer t(h, cls, fl);
@@ -618,7 +619,7 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
                                       {AF_NET_MAP1, tile_range(bm, T2, NT_map), nseg * N}})) != 0) return rc;
     if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_MAP1, tile_range(bm, 0, T1), nseg * N}})) != 0) return rc;
   }
-  const double dwf = (double)nseg * N * kFlopFwd[AF_NET_MAP1] + 3.0 * N * kFlopFwd[AF_NET_ATLAS];
+  const double dwf = (double)nseg * N * h->flop_fwd[AF_NET_MAP1] + 3.0 * N * h->flop_fwd[AF_NET_ATLAS];
   return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
 }
 
@@ -687,7 +688,7 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     if ((rc = launch_bwd(h, T_BWD_2, {{AF_NET_ALPHA, tile_range(bal, 0, T_al), 5 * N}, {AF_NET_MAP1, with_live(bwd_args(h, M1, NT_map, h->mlp_mode != 0), h, flow_base), nseg * N},
                                       {AF_NET_MAP2, with_live(bwd_args(h, M2, NT_map, h->mlp_mode != 0), h, flow_base), nseg * N}})) != 0) return rc;
   }
-  const double dwf = (double)nseg * N * (kFlopFwd[AF_NET_MAP1] + kFlopFwd[AF_NET_MAP2]) + 6.0 * N * kFlopFwd[AF_NET_ATLAS] + 5.0 * N * kFlopFwd[AF_NET_ALPHA];
+  const double dwf = (double)nseg * N * (h->flop_fwd[AF_NET_MAP1] + h->flop_fwd[AF_NET_MAP2]) + 6.0 * N * h->flop_fwd[AF_NET_ATLAS] + 5.0 * N * h->flop_fwd[AF_NET_ALPHA];
   return finish_step(h, sc, h->adam_m, h->adam_v, h->adam_step, loss_out, (N + 255) / 256, dwf);
 }
 
@@ -754,7 +755,8 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (cfg->resx <= 1 || cfg->resy <= 1 || cfg->number_of_frames <= 0) return bad("resx/resy/number_of_frames");
   if (cfg->samples_batch <= 0) return bad("samples_batch");
   if (cfg->number_of_channels_mapping1 != AF_HID || cfg->number_of_channels_atlas != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:19,24)");
-  if (cfg->number_of_layers_mapping1 != 6 || cfg->number_of_layers_atlas != 8) return bad("only 6-layer mapping / 8-layer atlas nets are built (config_flow_100.json:20,25)");
+  auto layers_ok = [](int n) { return n >= 2 && n <= AF_MAX_LAYERS; };
+  if (!layers_ok(cfg->number_of_layers_mapping1) || !layers_ok(cfg->number_of_layers_atlas)) return bad("number_of_layers_mapping1 / number_of_layers_atlas must be 2..8");
   if (cfg->positional_encoding_num_atlas != 10) return bad("positional_encoding_num_atlas must be 10");
   if (cfg->use_positional_encoding_mapping1) return bad("use_positional_encoding_mapping1=true is not built");
   if (!cfg->use_gradient_loss) return bad("use_gradient_loss=false is not built");
@@ -762,7 +764,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   const bool seg = cfg->two_layer != 0;
   if (seg) {
     if (cfg->number_of_channels_mapping2 != AF_HID || cfg->number_of_channels_alpha != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:21,26)");
-    if (cfg->number_of_layers_mapping2 != 4 || cfg->number_of_layers_alpha != 8) return bad("only 4-layer mapping2 / 8-layer alpha nets are built (config_flow_100.json:22,27)");
+    if (!layers_ok(cfg->number_of_layers_mapping2) || !layers_ok(cfg->number_of_layers_alpha)) return bad("number_of_layers_mapping2 / number_of_layers_alpha must be 2..8");
     if (cfg->positional_encoding_num_alpha != 5) return bad("positional_encoding_num_alpha must be 5");
     if (cfg->use_positional_encoding_mapping2) return bad("use_positional_encoding_mapping2=true is not built");
     if (cfg->global_rigidity_derivative_amount_bg <= 0) return bad("global_rigidity_derivative_amount_bg");
@@ -784,11 +786,20 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init()); CCHK((hipError_t)af_mlp_bf_init());
 
-  describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, 6, AF_IN_XYT, 0, 2, 0u, false);
-  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, 8, AF_IN_PE2, 10, 3, (1u << 4) | (1u << 7), true);
+  // layer counts come from the config (stage1_neural_atlas.py:112-128, _seg.py:127-161); the atlas net's skip_layers=[4, 7] apply to the
+  // layers it has (implicit_neural_networks.py:40-44: `if i in skip_layers` for i < num_layers, the output layer included)
+  const int nl_atlas = cfg->number_of_layers_atlas;
+  const unsigned atlas_skip = (nl_atlas > 4 ? (1u << 4) : 0u) | (nl_atlas > 7 ? (1u << 7) : 0u);
+  describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false);
+  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, 10, 3, atlas_skip, true);
   if (seg) {
-    describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, 4, AF_IN_XYT, 0, 2, 0u, false);
-    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, 8, AF_IN_PE3, 5, 1, 0u, false);
+    describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false);
+    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, 5, 1, 0u, false);
+  }
+  for (NetDesc& n : h->nets) if (n.used) {
+    double f = 0, d = n.dx0 ? (double)n.in_feat0 * AF_HID : 0.0;
+    for (int l = 0; l < n.NL; ++l) { f += (double)n.in_feat[l] * n.out_feat[l]; if (l >= 1) d += (double)AF_HID * n.out_feat[l]; }
+    h->flop_fwd[n.id] = 2.0 * f; h->flop_dx[n.id] = 2.0 * d;
   }
   size_t fc = 0, bc = 0, biasc = 0, pc = 0;
   for (NetDesc& n : h->nets) if (n.used) {
@@ -1053,13 +1064,13 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
       // 16-row chains (mlp16.hip): the batch is smaller than one round of the chip, so a step is bound by the latency
       // of one tile chain — half the rows per wave, half the latency
-      { Timer t(h, T_FWD_1, (double)NB * kFlopFwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
+      { Timer t(h, T_FWD_1, (double)NB * h->flop_fwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
         if (af_launch_fwd16(net, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      { Timer t(h, T_BWD_2, (double)NB * kFlopDx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
+      { Timer t(h, T_BWD_2, (double)NB * h->flop_dx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
         if (af_launch_bwd16(net, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
-      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * kFlopFwd[net], false);
+      rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * h->flop_fwd[net], false);
     }
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
@@ -1152,7 +1163,7 @@ int af_step_work(const af_handle* h, int iter, int64_t rows4[4], double* flops) 
   const int64_t nseg = glob_on(h->cfg, iter) ? 9 : 7, N = h->N;
   int64_t r[4] = {nseg * N, (h->seg ? 6 : 3) * N, h->seg ? nseg * N : 0, h->seg ? 5 * N : 0};
   double f = 0;
-  for (int i = 0; i < 4; ++i) { if (rows4) rows4[i] = r[i]; f += (double)r[i] * (2.0 * kFlopFwd[i] + kFlopDx[i]); }
+  for (int i = 0; i < 4; ++i) { if (rows4) rows4[i] = r[i]; f += (double)r[i] * (2.0 * h->flop_fwd[i] + h->flop_dx[i]); }
   if (flops) *flops = f;
   return AF_OK;
 }

@@ -31,7 +31,8 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
 
-  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS, tid);
+  const int nl = a.nl;
+  stage_bias(nl, a.bias, smem + AF_BIAS_LDS, tid);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
   float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
   {
@@ -120,7 +121,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   relu_out(0);
 
   // ---- hidden layers 1 .. NL-2
-  for (int l = 1; l <= NS::NL - 2; ++l) {
+  for (int l = 1; l <= nl - 2; ++l) {
     init_bias(acc, smem + AF_BIAS_LDS, l, h);
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
@@ -138,7 +139,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   // activation register as it stands (lane = row, register = feature 8g+4h+p) and the A operand is W[l & 3][8g+4h+p]
   // — the usual packed image with Mpad = 4.  Each k-half accumulates its own partial; one cross-half shuffle adds them.
   {
-    const char* buf = cs.next<CB::LAST>();
+    const char* buf = cs.next_rt(CB::last_bytes(nl));
     if constexpr (TRAIN) {     // the last hidden layer's activation tile (after the barrier: its wait must not cover them)
       ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
       ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
@@ -153,15 +154,17 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], in[4 * g + p], o4[p], 0, 0, 0);
     }
-    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) {
+    if constexpr (NS::SKIP != 0) {
+      if (CB::out_skip(nl)) {
 #pragma unroll
-      for (int g = 0; g < NS::PEG; ++g) {
-        const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
+        for (int g = 0; g < NS::PEG; ++g) {
+          const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+          for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+        }
       }
     }
-    const f32x4 bias = *(const f32x4*)(smem + AF_BIAS_LDS + (NS::NL - 1) * AF_HID * 4);
+    const f32x4 bias = *(const f32x4*)(smem + AF_BIAS_LDS + (nl - 1) * AF_HID * 4);
     f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -193,6 +196,7 @@ AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
   using CB = ChunkBytes<NS>;
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
+  const int nl = a.nl;
 
   float dzl[4];
   {
@@ -228,9 +232,9 @@ AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
 
   // ---- output layer: K = 8 (one group), only p < OUT non-zero
   { const char* buf = cs.next<CB::BLAST>(); mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, buf + a_off8, hook_dma); }
-  mask_out(NS::NL - 1);
+  mask_out(nl - 1);
 
-  for (int l = NS::NL - 2; l >= 1; --l) {
+  for (int l = nl - 2; l >= 1; --l) {
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4, true>(acc, in, buf + a_off8, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 64, 4>(acc, in, buf + a_off8, hook_dma); }
@@ -325,10 +329,10 @@ extern "C" int af_launch_bwd_multi(MultiBwd* m, hipStream_t s) {
 
 // The chunk sizes the kernels assume, for the host planner to check its layout against:
 // which = 0 fwd layer 0, 1 hidden quarter, 2 skip columns, 3 fwd output layer, 4 bwd output layer, 5 bwd layer 0.
-extern "C" int af_mlp_chunk_bytes(int net, int which) {
+extern "C" int af_mlp_chunk_bytes(int net, int which, int nl) {     // nl: layers of the net (the output-layer chunk is longer when it carries skip columns)
   auto pick = [&](auto ns) -> int {
     using CB = ChunkBytes<decltype(ns)>;
-    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::LAST, CB::BLAST, CB::BL0};
+    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::last_bytes(nl), CB::BLAST, CB::BL0};
     return which >= 0 && which < 6 ? v[which] : -1;
   };
   switch (net) {

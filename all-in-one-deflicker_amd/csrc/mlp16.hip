@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
 
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
-  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS, tid);
+  const int nl = a.nl;
+  stage_bias(nl, a.bias, smem + AF_BIAS_LDS, tid);
 
   float x0[4];
   {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
   { const char* buf = cs.next<CB::L0>(); init_bias(0); mm16<16, 256, 1, 0, 4>(acc, x0, buf + a_off, hook_dma); }
   relu_out(0);
 
-  for (int l = 1; l <= NS::NL - 2; ++l) {
+  for (int l = 1; l <= nl - 2; ++l) {
     init_bias(l);
     { const char* buf = cs.next<CB::HID>(); mm16<16, 256, 4, 0, 4>(acc, in, buf + a_off, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm16<16, 256, 4, 16, 4>(acc, in, buf + a_off, hook_dma); }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
   // ---- output layer on 4x4x1 MFMA blocks (Mpad-4 image, see mlp.hip): lane l = block (l >> 2) = (k-quad q, row quad),
   // column l & 3; A = W[l & 3][16T + 4q + r] = slot 4T + q of the image, B = in[4T + r]; four k-quads -> two shuffles.
   {
-    const char* buf = cs.next<CB::LAST>();
+    const char* buf = cs.next_rt(CB::last_bytes(nl));
     ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
     f32x4 o4[4];
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o4[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[r], in[4 * T + r], o4[r], 0, 0, 0);
     }
-    const f32x4 bias = *(const f32x4*)(smem + AF_BIAS_LDS + (NS::NL - 1) * AF_HID * 4);
+    const f32x4 bias = *(const f32x4*)(smem + AF_BIAS_LDS + (nl - 1) * AF_HID * 4);
     f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_bwd(BwdArgs a) {
 
   ChunkStream cs{nullptr, smem, wave, 0, nullptr, 0};
   cs.start(a.wimg, tid);
+  const int nl = a.nl;
 
   float dzl[4];
   {
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_bwd(BwdArgs a) {
   // output layer: W_last^T image (Mpad 256), one group of 16 k = out features of which OUT (k-quad 0) are real;
   // k-quads 2, 3 read past the 8 KB image (next layer's weights, finite) against B = 0
   { const char* buf = cs.next<CB::BLAST>(); mm16<16, 256, 1, 0, NS::OUT, true>(acc, dzl, buf + a_off, hook_dma); }
-  mask_out(NS::NL - 1);
+  mask_out(nl - 1);
 
-  for (int l = NS::NL - 2; l >= 1; --l) {
+  for (int l = nl - 2; l >= 1; --l) {
     { const char* buf = cs.next<CB::HID>(); mm16<16, 256, 4, 0, 4, true>(acc, in, buf + a_off, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm16<16, 256, 4, 16, 4>(acc, in, buf + a_off, hook_dma); }
     { const char* buf = cs.next<CB::HID>(); mm16<16, 256, 4, 32, 4>(acc, in, buf + a_off, hook_dma); }

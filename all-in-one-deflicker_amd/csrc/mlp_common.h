@@ -10,6 +10,7 @@
                    // sched_barrier, bit5 no operand split, bit6 only wave 0 issues the LDS-DMA, bit8 atlas PE without sin / cos, bit9 with sincosf
 #endif
 
+// NL is the SHIPPED layer count (config_flow_100.json); the kernels take the actual count from FwdArgs::nl / BwdArgs::nl.
 struct NsMap1  { static constexpr int NL = 6, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsMap2  { static constexpr int NL = 4, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsAtlas { static constexpr int NL = 8, IN = AF_IN_PE2, K0G = 5, PEG = 5, OUT = 3; static constexpr unsigned SKIP = (1u << 4) | (1u << 7);   static constexpr bool DX0 = true;  };
@@ -23,7 +24,11 @@ template <class NS> struct ChunkBytes {
   static constexpr int L0   = af_round4k(NS::K0G * 2 * AF_HID * 16);                                            // forward layer 0
   static constexpr int HID  = 8 * 2 * AF_HID * 16;                                                            // a quarter of a 256x256 layer = 64 KB
   static constexpr int SKIP = af_round4k(NS::PEG * 2 * AF_HID * 16);                                            // PE columns of a skip layer
-  static constexpr int LAST = af_round4k((32 + (((NS::SKIP >> (NS::NL - 1)) & 1) ? NS::PEG : 0)) * 2 * 4 * 16);    // forward output layer (Mpad 4)
+  static constexpr int LASTN = af_round4k(32 * 2 * 4 * 16);                                                   // forward output layer (Mpad 4) ...
+  static constexpr int LASTS = af_round4k((32 + NS::PEG) * 2 * 4 * 16);                                       // ... with the PE columns of a skip-concat in front of it
+  static constexpr bool out_skip(int nl) { return ((NS::SKIP >> (nl - 1)) & 1u) != 0; }                       // implicit_neural_networks.py:40-44: layer i in skip_layers, i == num_layers - 1
+  static constexpr int last_bytes(int nl) { return out_skip(nl) ? LASTS : LASTN; }
+  static constexpr int LAST = last_bytes(NS::NL);
   static constexpr int BLAST = 2 * AF_HID * 16;                                                               // backward output layer: one k-group
   static constexpr int BL0  = 32 * 2 * 64 * 16;                                                               // backward layer 0 (Mpad 64 PE slots)
 };
@@ -51,7 +56,8 @@ struct ChunkStream {
   // arm the staging of chunk cidx+1 — which starts BYTES further on — into the buffer chunk cidx-1 used.
   // Returns the LDS base of chunk cidx.  After the last chunk the stream stages 64 KB of whatever follows
   // (the image buffers are padded for that) into the idle buffer: harmless, and the issue sites stay branch-free.
-  template <int BYTES> AF_DEV const char* next() {
+  template <int BYTES> AF_DEV const char* next() { return next_rt(BYTES); }
+  AF_DEV const char* next_rt(int BYTES) {
     while (p_it < 16) issue2();
     if constexpr (!(AF_ABL & 4)) { af_wait_vm0(); __syncthreads(); }
     const int cur = cidx;
@@ -80,10 +86,9 @@ template <class Args> AF_DEV int live_tiles(const Args& a) {
   return nt < a.NT ? nt : a.NT;
 }
 
-template <int NL> AF_DEV void stage_bias(const float* bias, char* bias_lds, int tid) {
+AF_DEV void stage_bias(int nl, const float* bias, char* bias_lds, int tid) {
   float* dst = (float*)bias_lds;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) dst[i * AF_HID + tid] = bias[i * AF_HID + tid];     // 256 threads x NL rows; visible after the first barrier
+  for (int i = 0; i < nl; ++i) dst[i * AF_HID + tid] = bias[i * AF_HID + tid];     // 256 threads x nl rows; visible after the first barrier
 }
 
 // ---- blocks shared by the fp32 chains (mlp.hip) and the bf16x6 chains (mlpbf.hip) ----------------------------------------

@@ -31,6 +31,8 @@ template <class NS> struct ChunkBytesBf {
   static constexpr int HID = AF_SLOT_BF;                 // x8 per hidden layer
   static constexpr int SKIP = ChunkBytes<NS>::SKIP;
   static constexpr int LAST = ChunkBytes<NS>::LAST;
+  static constexpr bool out_skip(int nl) { return ChunkBytes<NS>::out_skip(nl); }
+  static constexpr int last_bytes(int nl) { return ChunkBytes<NS>::last_bytes(nl); }
   static constexpr int BLAST = ChunkBytes<NS>::BLAST;
   static constexpr int BL0H = 16 * 2 * 64 * 16;          // half of the backward layer-0 block (Mpad 64): two chunks of 32 KB
 };
@@ -330,7 +332,8 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
   using CB = ChunkBytesBf<NS>;
   BfStream cs; cs.smem = smem;
   cs.start(a.wimg, tid, wave);
-  stage_bias<NS::NL>(a.bias, smem + AF_BIAS_LDS_BF, tid);
+  const int nl = a.nl;
+  stage_bias(nl, a.bias, smem + AF_BIAS_LDS_BF, tid);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
   float pe[NPE];            // first-layer / skip B operand (PE features, or xyt for the mapping nets)
   {
@@ -408,24 +411,23 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
     }
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
-  auto hook_store = [&](auto gi) { if constexpr (TRAIN) ts.template part<decltype(gi)::value>(in); };
 
   // ---- layer 0 (fp32 block); the chunk behind it is the first bf16 chunk of layer 1
   const char* cur = cs.publish(CB::L0);             // its barrier also publishes the bias rows
   init_bias(acc, bias_lds, 0, h);
   mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
   relu_out(0);
-  const char* lane_base = cs.publish(CB::HID) + lane_off;
+  const char* lane_base = cs.publish(nl > 2 ? CB::HID : CB::last_bytes(nl)) + lane_off;     // what lies behind layer 0: the first hidden chunk, or the output layer
   cs.lead5();
 
   // ---- hidden layers 1 .. NL-2: eight bf16 chunks each (+ the fp32 block of the skip columns); every iteration runs the
   // same code — what lies behind a layer (its skip block, the next layer's first chunk, the output layer) is only a size
 #pragma unroll 1
-  for (int l = 1; l <= NS::NL - 2; ++l) {
+  for (int l = 1; l <= nl - 2; ++l) {
     init_bias(acc, bias_lds, l, h);
     bf_enter(pp, in, lane_base);
     const bool skip = NS::SKIP != 0 && ((NS::SKIP >> l) & 1);
-    const int behind = l == NS::NL - 2 ? CB::LAST : CB::HID;
+    const int behind = l == nl - 2 ? CB::last_bytes(nl) : CB::HID;
     bf_block<false, 6, ((TRAIN && !(AF_ABL & 1)) ? 16 : 0)>(acc, in, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, ts);
     if constexpr (NS::SKIP != 0) {
       if (skip) {
@@ -455,15 +457,17 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], in[4 * g + p], o4[p], 0, 0, 0);
     }
-    if constexpr ((NS::SKIP >> (NS::NL - 1)) & 1) {
+    if constexpr (NS::SKIP != 0) {
+      if (CB::out_skip(nl)) {
 #pragma unroll
-      for (int g = 0; g < NS::PEG; ++g) {
-        const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
+        for (int g = 0; g < NS::PEG; ++g) {
+          const f32x4 w = *(const f32x4*)(al + (32 + g) * 2 * 4 * 16);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+          for (int p = 0; p < 4; ++p) o4[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[p], pe[4 * g + p], o4[p], 0, 0, 0);
+        }
       }
     }
-    const f32x4 bias = *(const f32x4*)(bias_lds + (NS::NL - 1) * AF_HID * 4);
+    const f32x4 bias = *(const f32x4*)(bias_lds + (nl - 1) * AF_HID * 4);
     f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -504,6 +508,7 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
   using CB = ChunkBytesBf<NS>;
   BfStream cs; cs.smem = smem;
   cs.start(a.wimg, tid, wave);
+  const int nl = a.nl;
 
   float dzl[4];
   {
@@ -532,18 +537,17 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
-  auto hook_store = [&](auto gi) { ts.template part<decltype(gi)::value>(in); };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
 
   // ---- output layer (fp32 block): K = 8 (one group), only p < OUT non-zero
   const char* cur = cs.publish(CB::BLAST);
   mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
-  mask_out(NS::NL - 1);
-  const char* lane_base = cs.publish(CB::HID) + lane_off;
+  mask_out(nl - 1);
+  const char* lane_base = cs.publish(nl > 2 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096)) + lane_off;
   cs.lead5();
 
 #pragma unroll 1
-  for (int l = NS::NL - 2; l >= 1; --l) {
+  for (int l = nl - 2; l >= 1; --l) {
     bf_enter(pp, in, lane_base);
     // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
     bf_block<true, NPROD, ((AF_ABL & 1) ? 0 : 16)>(acc, in, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), ts);
@@ -657,10 +661,10 @@ extern "C" int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s) {
 }
 // chunk sizes of the bf16 streams for the host planner: which = 0 fwd layer 0, 1 bf16 hidden chunk (x8 per layer), 2 skip columns,
 // 3 fwd output layer, 4 bwd output layer, 5 half of bwd layer 0 (x2)
-extern "C" int af_mlp_chunk_bytes_bf(int net, int which) {
+extern "C" int af_mlp_chunk_bytes_bf(int net, int which, int nl) {     // nl: layers of the net (the output-layer chunk is longer when it carries skip columns)
   auto pick = [&](auto ns) -> int {
     using CB = ChunkBytesBf<decltype(ns)>;
-    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::LAST, CB::BLAST, CB::BL0H};
+    const int v[6] = {CB::L0, CB::HID, CB::SKIP, CB::last_bytes(nl), CB::BLAST, CB::BL0H};
     return which >= 0 && which < 6 ? v[which] : -1;
   };
   switch (net) {

@@ -1,0 +1,64 @@
+"""Architectures other than the shipped one (config keys number_of_layers_*, stage1_neural_atlas.py:112-128, _seg.py:127-161):
+forward outputs of the REFERENCE's own `IMLP` for a set of layer counts of every net kind, on seeded rows and seeded
+torch-default weights -> tests/golden/arch_variants.npz.  The GPU test (tests/test_gpu_arch.py) re-creates the same weights
+from the seed (nn.Linear init in construction order, RNG-only) and holds the HIP chains against these outputs; the oracle
+restatement (oracle/atlas_oracle.py:OracleIMLP) is checked against them here as well.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_arch.py          (build container only: imports /root/reference read-only)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("AF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+for _name in ("cv2", "imageio"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+
+from src.models.stage_1.implicit_neural_networks import IMLP      # noqa: E402
+from oracle import atlas_oracle as O                                # noqa: E402
+
+# kind -> (input_dim, output_dim, use_positional, positional_dim, skip_layers)      (the constructor calls of the two stage-1 scripts)
+KINDS = {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "alpha": (3, 1, True, 5, [])}
+VARIANTS = [("mapping", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("atlas", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("alpha", n) for n in (2, 3, 5, 8)]
+ROWS = 96
+
+
+def main():
+    out = {}
+    for kind, nl in VARIANTS:
+        ind, outd, pos, pdim, skips = KINDS[kind]
+        seed = 7000 + 10 * nl + len(kind)
+        torch.manual_seed(seed)
+        ref = IMLP(input_dim=ind, output_dim=outd, hidden_dim=256, use_positional=pos, positional_dim=pdim, num_layers=nl, skip_layers=skips, verbose=False)
+        torch.manual_seed(seed)
+        ora = O.OracleIMLP(ind, outd, 256, pos, pdim, skips, nl)
+        for (kn, pr), (_, po) in zip(ref.state_dict().items(), ora.state_dict().items()):
+            assert torch.equal(pr, po), (kind, nl, kn)
+        g = torch.Generator().manual_seed(seed + 1)
+        rows = torch.rand(ROWS, ind, generator=g) * 2 - 1
+        with torch.no_grad():
+            y = ref(rows)
+            assert torch.equal(y, ora(rows)), (kind, nl)
+        key = "%s_%d" % (kind, nl)
+        out[key + "_seed"] = seed
+        out[key + "_rows"] = rows.numpy()
+        out[key + "_out"] = y.numpy()
+        out[key + "_nparams"] = sum(p.numel() for p in ref.parameters())
+        print(key, "params", out[key + "_nparams"], "out[0]", y[0].numpy())
+    if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
+        print("arch variants: restatement == reference IMLP (check only)")
+        return
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "arch_variants.npz"), variants=np.array(["%s_%d" % v for v in VARIANTS]), **out)
+    print("written tests/golden/arch_variants.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Architectures other than the shipped one: the config's number_of_layers_* keys (stage1_neural_atlas.py:112-128,
+stage1_neural_atlas_seg.py:127-161; implicit_neural_networks.py:16-60) select 2..8 layers per net — the layer loops of the
+chains are runtime loops, the atlas net's skip_layers = [4, 7] apply to the layers it has (a skip on the OUTPUT layer when
+num_layers is 5 or 8).  Forward outputs of every variant against a fixture written from the reference's own `IMLP`
+(oracle/make_golden_arch.py -> tests/golden/arch_variants.npz), in both arithmetics of the chains, and complete training steps
+of two non-shipped configurations (single atlas and fg/bg) against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arch_variants.npz")
+
+
+def _state_dict(seed, shapes):
+    """nn.Linear init in construction order under torch.manual_seed(seed): what IMLP.__init__ draws."""
+    torch.manual_seed(seed)
+    sd = {}
+    for i, (o, k) in enumerate(shapes):
+        lin = torch.nn.Linear(k, o)
+        sd["hidden.%d.weight" % i] = lin.weight.detach(); sd["hidden.%d.bias" % i] = lin.bias.detach()
+    return sd
+
+
+def _variants(g, kind):
+    return [int(v.split("_")[1]) for v in g["variants"] if v.startswith(kind + "_")]
+
+
+@pytest.mark.parametrize("mlp_mode", [1, 0])
+def test_forward_of_every_layer_count_matches_reference_imlp(mlp_mode):
+    import aiod_amd
+    A = aiod_amd.atlasfit
+    g = dict(np.load(GOLDEN))
+    worst = {}
+    for kind, net, key, width in (("mapping", A.NET_MAPPING1, "number_of_layers_mapping1", 3), ("mapping", A.NET_MAPPING2, "number_of_layers_mapping2", 3),
+                                  ("atlas", A.NET_ATLAS, "number_of_layers_atlas", 2), ("alpha", A.NET_ALPHA, "number_of_layers_alpha", 3)):
+        for nl in _variants(g, kind):
+            name = "%s_%d" % (kind, nl)
+            cfg = A.default_config(64, 48, 4, {key: nl}, two_layer=True)
+            af = aiod_amd.AtlasFit(cfg)
+            try:
+                af.set_mlp_mode(mlp_mode)
+                assert af.param_count(net) == int(g[name + "_nparams"]), (name, af.param_count(net))
+                af.load_state_dict(net, _state_dict(int(g[name + "_seed"]), A.imlp_shapes(net, cfg)))
+                rows = np.zeros((g[name + "_rows"].shape[0], 4), np.float32); rows[:, :width] = g[name + "_rows"]
+                out = af.debug_forward(net, rows)
+                want = g[name + "_out"]
+                err = float(np.abs(out[:, :want.shape[1]] - want).max())
+                worst[(name, net)] = err
+                assert err < 5e-6, (name, net, mlp_mode, err)
+            finally:
+                af.close()
+    print("mlp_mode %d: worst forward distance from the reference IMLP over %d variants: %.3g" % (mlp_mode, len(worst), max(worst.values())))
+
+
+@pytest.mark.parametrize("two_layer,layers", [(False, dict(number_of_layers_mapping1=3, number_of_layers_atlas=5)),
+                                              (False, dict(number_of_layers_mapping1=8, number_of_layers_atlas=2)),
+                                              (True, dict(number_of_layers_mapping1=4, number_of_layers_mapping2=2, number_of_layers_atlas=6, number_of_layers_alpha=3))])
+def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, layers, golden, golden_seg, small_video, small_seg_video):
+    """Three Adam steps of the whole loop (forward, loss stack, backward, dW, Adam) on the fixture video with other layer counts:
+    every loss term within 1e-3 of the CPU oracle built from the same config, end weights close, pre_train_mapping included."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    A = aiod_amd.atlasfit
+    gd = golden_seg if two_layer else golden
+    v = small_seg_video if two_layer else small_video
+    cfg = dict(gd["config"]); cfg.update(layers)
+    c = A.default_config(int(gd["resx"]), int(gd["resy"]), int(gd["nframes"]), cfg, two_layer=two_layer, pretrain_batch=512)
+    af = aiod_amd.AtlasFit(c)
+    try:
+        if two_layer:
+            af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask, v.mask_frames)
+            models = O.build_seg_models(cfg, seed=77)
+            nets = (A.NET_MAPPING1, A.NET_MAPPING2, A.NET_ATLAS, A.NET_ALPHA)
+        else:
+            af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
+            models = O.build_single_atlas_models(cfg, seed=77)
+            nets = (A.NET_MAPPING1, A.NET_ATLAS)
+        for net, m in zip(nets, models):
+            af.load_state_dict(net, m.state_dict())
+        # the 16-row pre-train chains with this depth: a few steps on the device, state copied into the oracle
+        af.pre_train_mapping(1, seed=3)
+        if two_layer:
+            af.pre_train_mapping(1, seed=4, net=A.NET_MAPPING2)
+        for net, m in zip(nets, models):
+            flat, off = af.get_params_flat(net), 0
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.copy_(torch.from_numpy(flat[off:off + p.numel()].reshape(p.shape))); off += p.numel()
+            z = np.zeros(af.param_count(net), np.float32)
+            af.set_adam_state(net, z, z, 0)
+        tr = O.SegAtlasTrainer(cfg, v, models=models) if two_layer else O.SingleAtlasTrainer(cfg, v, mapping=models[0], atlas=models[1])
+        N = int(cfg["samples_batch"])
+        gen = torch.Generator().manual_seed(5)
+        K = 3
+        inds = torch.randint(v.F * v.resx * v.resy, (K, N), generator=gen)
+        hip = af.train_steps(0, K, inds.numpy())
+        names = O.SEG_TERMS if two_layer else ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+        for k in range(K):
+            t = tr.step(k, inds[k])
+            want = np.array([t[n] for n in names])
+            got = hip[k, :len(names)]
+            on = np.abs(want) > 0
+            rel = np.abs(got[on] - want[on]) / np.abs(want[on])
+            print(layers, "iteration", k, "max rel %.3g" % rel.max())
+            assert rel.max() < 1e-3, (layers, k, got, want)
+        for net, m in zip(nets, models):
+            d = np.abs(af.get_params_flat(net) - O.flat_params(m))
+            assert d.max() < 1e-3 and d.mean() < 3e-5, (layers, net, d.max(), d.mean())
+    finally:
+        af.close()
+
+
+def test_layer_counts_outside_2_to_8_are_rejected():
+    import aiod_amd
+    A = aiod_amd.atlasfit
+    for key, bad in (("number_of_layers_mapping1", 1), ("number_of_layers_atlas", 9), ("number_of_layers_alpha", 0)):
+        with pytest.raises(aiod_amd.AtlasFitError):
+            aiod_amd.AtlasFit(A.default_config(64, 48, 4, {key: bad}, two_layer=True))

@@ -188,6 +188,59 @@ def test_full_size_seg_iteration_matches_oracle():
     torch.cuda.empty_cache()
 
 
+def test_full_size_seg_trajectory_matches_oracle():
+    """BASELINE configs[4] at its real size over CONSECUTIVE Adam steps (the full-size fg/bg evidence was single-step):
+    both mapping nets pre-trained on the device, the state copied into the CPU oracle, then TEN iterations of the four-net packed
+    launch plan on the same injected indices straddling the global-rigidity switch (i = 4996..5005, stage1_neural_atlas_seg.py:
+    193-315, stop_global_rigidity 5000): all 12 loss terms of every iteration within BASELINE.json's 1e-3, end weights close."""
+    import aiod_amd
+    import bench
+    from oracle import atlas_oracle as O
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 80
+    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev)
+    fg = bench.synth_fg_mask_device(resx, resy, F, seed=2, device=dev)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=True))
+    af.upload_video(*video, fg)
+    nets = (aiod_amd.NET_MAPPING1, aiod_amd.NET_MAPPING2, aiod_amd.NET_ATLAS, aiod_amd.NET_ALPHA)
+    sds = bench.init_state_dicts(977, two_layer=True)
+    for net in nets:
+        af.load_state_dict(net, sds[net])
+    af.pre_train_mapping(2, seed=7, net=aiod_amd.NET_MAPPING1)
+    af.pre_train_mapping(2, seed=8, net=aiod_amd.NET_MAPPING2)
+    for net in nets:
+        z = np.zeros(af.param_count(net), np.float32)
+        af.set_adam_state(net, z, z, 0)
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    frames, flows, flows_rev, mask, mask_rev = [t.cpu() for t in video]
+    v = O.SegVideo(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None], fg.cpu())
+    models = O.build_seg_models(cfg, seed=0)
+    _copy_params_to_oracle(af, nets, models)
+    tr = O.SegAtlasTrainer(cfg, v, models=models)
+    g = torch.Generator().manual_seed(29)
+    K, first, N = 10, 4996, cfg["samples_batch"]
+    inds = torch.randint(F * resx * resy, (K, N), generator=g)
+    hip = af.train_steps(first, K, inds.numpy())
+    worst = 0.0
+    for k in range(K):
+        t = tr.step(first + k, inds[k])
+        want = np.array([t[n] for n in O.SEG_TERMS])
+        on = np.abs(want) > 0
+        rel = np.zeros(12)
+        rel[on] = np.abs(hip[k, :12][on] - want[on]) / np.abs(want[on])
+        assert np.all(hip[k, :12][~on] == 0), (first + k, hip[k, :12], want)       # the switched-off global terms are exactly zero on both sides
+        print(first + k, "rel max %.3g" % rel.max(), "global terms", want[4], want[5])
+        assert rel.max() < 1e-3, (first + k, hip[k, :12], want, rel)
+        assert (want[4] > 0) == (first + k <= 5000) and (want[5] > 0) == (first + k <= 5000)
+        worst = max(worst, float(rel.max()))
+    print("full-size two-layer trajectory: worst relative loss-term distance %.3g over %d iterations" % (worst, K))
+    for net, mdl in zip(nets, models):
+        d = np.abs(af.get_params_flat(net) - O.flat_params(mdl))
+        print("end-weight diff net", net, "max %.3g mean %.3g" % (d.max(), d.mean()))
+        assert d.max() < 1.5e-3 and d.mean() < 3e-5        # Adam: a ~0 gradient whose sign differs moves a weight by 2*lr per step
+    af.close()
+
+
 def test_full_size_is_bit_reproducible_and_finite(full):
     import aiod_amd
     af, video, sds = full

@@ -59,9 +59,9 @@ int main(int argc, char** argv) {
   std::vector<float> w(img_bytes / 4); for (auto& x : w) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
   CK(hipMemcpy(img, w.data(), img_bytes, hipMemcpyHostToDevice));
   FwdArgs fa{}; fa.wimg = img; fa.bias = bias; fa.in = in; fa.in1 = nullptr; fa.out = out; fa.acts = acts; fa.masks = masks;
-  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.pe_tile = pe_tile;
+  fa.in_scale = 0.5f; fa.in_shift0 = 0.5f; fa.split_row = 1 << 30; fa.NT = NT; fa.nt_stride = NT; fa.pe_tile = pe_tile; fa.nl = only_net == 1 || only_net == 3 ? 8 : (only_net == 2 ? 4 : 6);
   BwdArgs ba{}; ba.wimg = img; ba.out = out; ba.dout = in; ba.masks = masks; ba.dz = dz; ba.dz_last = dzl;
-  ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT; ba.pe_tile = pe_tile;
+  ba.split_row = 1 << 30; ba.NT = NT; ba.nt_stride = NT; ba.pe_tile = pe_tile; ba.nl = fa.nl;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   if (argc > 2 && atoi(argv[2]) == 1) {     // ablate <NT> 1: the pure-MFMA ceiling
     CK(hipFuncSetAttribute((const void*)k_mfma_ceiling, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
