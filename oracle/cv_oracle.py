@@ -22,27 +22,37 @@ Known build-dependent detail NOT restated: OpenCV's AVX2/FMA3 dispatch of the fl
 
 Pinning: cv2 cannot be imported here, so this restatement is pinned by hand-computed vectors of the published
 algorithm (tests/test_cv_oracle.py); with cv2 installed the same test file compares against it directly
-(`pytest.importorskip("cv2")`).  Only tests/ import this module.
+(`pytest.importorskip("cv2")`) — PARITY UNPINNED against the real library until then.  Only tests/ import this module.
+
+Written as SCALAR loops in the order of OpenCV's own code (coefficient tables, a horizontal pass into row buffers, a vertical
+pass; a per-pixel fixed-point remap) with numpy scalar types doing the roundings — deliberately NOT the vectorised expressions of
+the product's host loader (all-in-one-deflicker_amd/stage1.py), so that the bit-equality the tests assert between the two
+(and the device kernels) compares two independent implementations.  Slow: test sizes only.
 """
+import math
+
 import numpy as np
 
 INTER_BITS = 5
 INTER_TAB_SIZE = 1 << INTER_BITS
+F32 = np.float32
 
 
 def _linear_coeffs(src, dst):
-    """resize.cpp: per destination index the first source tap and the two float coefficients."""
-    scale = float(src) / float(dst)                           # double
-    d = np.arange(dst, dtype=np.float64)
-    f = ((d + 0.5) * scale - 0.5).astype(np.float32)           # (float)((dx+0.5)*scale_x - 0.5)
-    s = np.floor(f).astype(np.int64)                           # cvFloor
-    f = (f - s.astype(np.float32)).astype(np.float32)          # fx -= sx   (float)
-    lo = s < 0
-    s[lo] = 0; f[lo] = 0.0
-    hi = s >= src - 1
-    s[hi] = src - 1; f[hi] = 0.0
-    a0 = (np.float32(1.0) - f).astype(np.float32)
-    return s, np.minimum(s + 1, src - 1), a0, f
+    """resize.cpp (resizeGeneric_ set-up loop): per destination index the first source tap, the second (clamped) tap and the
+    two float coefficients.  Returns (ofs, ofs1, a0, a1) as arrays."""
+    scale = float(src) / float(dst)                            # double scale_x = (double)ssize.width / dsize.width
+    ofs, ofs1, a0, a1 = [], [], [], []
+    for d in range(dst):
+        f = F32((d + 0.5) * scale - 0.5)                       # fx = (float)((dx + 0.5) * scale_x - 0.5)
+        s = int(math.floor(float(f)))                          # sx = cvFloor(fx)
+        f = F32(f - F32(s))                                    # fx -= sx
+        if s < 0:
+            s, f = 0, F32(0.0)
+        if s >= src - 1:
+            s, f = src - 1, F32(0.0)
+        ofs.append(s); ofs1.append(min(s + 1, src - 1)); a0.append(F32(F32(1.0) - f)); a1.append(f)
+    return np.array(ofs, np.int64), np.array(ofs1, np.int64), np.array(a0, np.float32), np.array(a1, np.float32)
 
 
 def cv_resize_linear(img, new_w, new_h):
@@ -52,52 +62,88 @@ def cv_resize_linear(img, new_w, new_h):
     h, w = img.shape[:2]
     if (h, w) == (new_h, new_w):
         return img.copy()                                      # cv::resize copies when the sizes agree
-    wt = img.dtype.type                                        # work type: float for CV_32F, double for CV_64F
-    sx, sx1, a0, a1 = _linear_coeffs(w, new_w)
-    sy, sy1, b0, b1 = _linear_coeffs(h, new_h)
-    shp = (1, new_w) + (1,) * (img.ndim - 2)
-    a0, a1 = a0.astype(wt).reshape(shp), a1.astype(wt).reshape(shp)
-    rows0 = img[sy][:, sx] * a0 + img[sy][:, sx1] * a1         # horizontal pass on the two source rows of each output row
-    rows1 = img[sy1][:, sx] * a0 + img[sy1][:, sx1] * a1
-    shp = (new_h, 1) + (1,) * (img.ndim - 2)
-    out = rows0 * b0.astype(wt).reshape(shp) + rows1 * b1.astype(wt).reshape(shp)
-    return out.astype(img.dtype)
+    wt = img.dtype.type                                        # work type WT: float for CV_32F, double for CV_64F
+    src = img.reshape(h, w, -1)
+    cn = src.shape[2]
+    xofs, xofs1, alpha0, alpha1 = _linear_coeffs(w, new_w)
+    yofs, yofs1, beta0, beta1 = _linear_coeffs(h, new_h)
+    out = np.empty((new_h, new_w, cn), img.dtype)
+    rows = {}                                                  # HResizeLinear results of the source rows in use (the ring of two row buffers)
+
+    def hresize(sy):
+        if sy not in rows:
+            buf = np.empty((new_w, cn), img.dtype)
+            for dx in range(new_w):
+                a0, a1 = wt(alpha0[dx]), wt(alpha1[dx])
+                for c in range(cn):
+                    buf[dx, c] = wt(src[sy, xofs[dx], c]) * a0 + wt(src[sy, xofs1[dx], c]) * a1
+            rows[sy] = buf
+        return rows[sy]
+
+    for dy in range(new_h):
+        r0, r1 = hresize(int(yofs[dy])), hresize(int(yofs1[dy]))
+        b0, b1 = wt(beta0[dy]), wt(beta1[dy])
+        for dx in range(new_w):
+            for c in range(cn):
+                out[dy, dx, c] = wt(r0[dx, c]) * b0 + wt(r1[dx, c]) * b1          # VResizeLinear
+        for k in [k for k in rows if k < int(yofs[dy])]:
+            del rows[k]
+    return out.reshape((new_h, new_w) + img.shape[2:])
 
 
 def cv_resize_flow(flow, newh, neww):
     """unwrap_utils.py:33-38 with cv2.resize restated (CV_32FC2: float arithmetic)."""
     oldh, oldw = flow.shape[:2]
     out = cv_resize_linear(np.asarray(flow, np.float32), neww, newh)
-    out[:, :, 0] *= np.float32(newh / oldh)
-    out[:, :, 1] *= np.float32(neww / oldw)
+    su, sv = F32(newh / oldh), F32(neww / oldw)
+    for y in range(newh):
+        for x in range(neww):
+            out[y, x, 0] = F32(out[y, x, 0] * su)
+            out[y, x, 1] = F32(out[y, x, 1] * sv)
     return out
+
+
+def _cv_round(v):
+    """cvRound of a float: round half to even (SSE cvtss2si / lrint)."""
+    return int(np.rint(v))
 
 
 def cv_remap_linear(img, mapxy):
     """cv2.remap(img, mapxy, None, cv2.INTER_LINEAR): img (H, W, C) float32, mapxy (h, w, 2) float32 (x, y); constant-0 border."""
     img = np.asarray(img, np.float32)
-    h, w = img.shape[:2]
-    q = np.rint(np.asarray(mapxy, np.float32) * np.float32(INTER_TAB_SIZE)).astype(np.int64)    # cvRound: half to even
-    ix, iy = q[..., 0] >> INTER_BITS, q[..., 1] >> INTER_BITS
-    fx = ((q[..., 0] & (INTER_TAB_SIZE - 1)).astype(np.float32) / np.float32(INTER_TAB_SIZE))[..., None]
-    fy = ((q[..., 1] & (INTER_TAB_SIZE - 1)).astype(np.float32) / np.float32(INTER_TAB_SIZE))[..., None]
-    one = np.float32(1.0)
-    w0, w1, w2, w3 = (one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx
-
-    def tap(yy, xx):
-        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
-        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
-        return np.where(ok[..., None], v, np.float32(0.0)).astype(np.float32)
-
-    return ((tap(iy, ix) * w0 + tap(iy, ix + 1) * w1) + tap(iy + 1, ix) * w2) + tap(iy + 1, ix + 1) * w3
+    mapxy = np.asarray(mapxy, np.float32)
+    h, w, cn = img.shape
+    oh, ow = mapxy.shape[:2]
+    out = np.empty((oh, ow, cn), np.float32)
+    one, tab = F32(1.0), F32(INTER_TAB_SIZE)
+    for y in range(oh):
+        for x in range(ow):
+            sx = _cv_round(F32(mapxy[y, x, 0] * tab)); sy = _cv_round(F32(mapxy[y, x, 1] * tab))      # fixed point, INTER_BITS = 5
+            ix, iy = sx >> INTER_BITS, sy >> INTER_BITS
+            fx = F32(F32(sx & (INTER_TAB_SIZE - 1)) / tab); fy = F32(F32(sy & (INTER_TAB_SIZE - 1)) / tab)
+            w0 = F32(F32(one - fy) * F32(one - fx)); w1 = F32(F32(one - fy) * fx); w2 = F32(fy * F32(one - fx)); w3 = F32(fy * fx)
+            for c in range(cn):
+                def tap(yy, xx):
+                    return img[yy, xx, c] if (0 <= xx < w and 0 <= yy < h) else F32(0.0)
+                v = F32(F32(tap(iy, ix) * w0) + F32(tap(iy, ix + 1) * w1))
+                v = F32(v + F32(tap(iy + 1, ix) * w2))
+                out[y, x, c] = F32(v + F32(tap(iy + 1, ix + 1) * w3))
+    return out
 
 
 def cv_compute_consistency(flow12, flow21):
     """unwrap_utils.py:10-23: || flow12 + warp_flow(flow21, flow12) || with cv2.remap restated."""
     flow12 = np.asarray(flow12, np.float32)
     h, w = flow12.shape[:2]
-    m = flow12.copy()
-    m[:, :, 0] += np.arange(w)                                 # float32 += int64 (one rounding of the exact sum)
-    m[:, :, 1] += np.arange(h)[:, np.newaxis]
-    diff = flow12 + cv_remap_linear(np.asarray(flow21, np.float32), m)
-    return (diff[:, :, 0] ** 2 + diff[:, :, 1] ** 2) ** .5
+    m = np.empty_like(flow12)
+    for y in range(h):
+        for x in range(w):
+            m[y, x, 0] = F32(flow12[y, x, 0] + F32(x))         # flow[:, :, 0] += np.arange(w): one rounding of the exact sum
+            m[y, x, 1] = F32(flow12[y, x, 1] + F32(y))
+    warped = cv_remap_linear(np.asarray(flow21, np.float32), m)
+    out = np.empty((h, w), np.float32)
+    for y in range(h):
+        for x in range(w):
+            du = F32(flow12[y, x, 0] + warped[y, x, 0]); dv = F32(flow12[y, x, 1] + warped[y, x, 1])
+            out[y, x] = F32(F32(F32(du * du) + F32(dv * dv)) ** F32(0.5))
+    return out
