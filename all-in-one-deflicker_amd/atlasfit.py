@@ -60,7 +60,8 @@ class AfConfig(C.Structure):
         ("stop_bootstrapping_iteration", C.c_int32),
         ("global_rigidity_coeff_bg", C.c_float),
         ("alpha_bootstrapping_factor", C.c_float), ("alpha_flow_factor", C.c_float), ("sparsity_coeff", C.c_float),
-        ("reserved", C.c_int32 * 4),
+        ("number_of_positional_encoding_mapping1", C.c_int32), ("number_of_positional_encoding_mapping2", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -98,6 +99,8 @@ def default_config(resx, resy, number_of_frames, config=None, two_layer=False, *
     c.number_of_layers_alpha = int(cfg["number_of_layers_alpha"])
     c.positional_encoding_num_alpha = int(cfg["positional_encoding_num_alpha"])
     c.use_positional_encoding_mapping2 = int(bool(cfg["use_positional_encoding_mapping2"]))
+    c.number_of_positional_encoding_mapping1 = int(cfg.get("number_of_positional_encoding_mapping1", 4))
+    c.number_of_positional_encoding_mapping2 = int(cfg.get("number_of_positional_encoding_mapping2", 2))
     c.global_rigidity_derivative_amount_bg = int(cfg["global_rigidity_derivative_amount_bg"])
     c.stop_bootstrapping_iteration = int(cfg["stop_bootstrapping_iteration"])
     c.global_rigidity_coeff_bg = float(cfg["global_rigidity_coeff_bg"])
@@ -207,6 +210,11 @@ def imlp_shapes(net, cfg=None, pe_atlas=10, pe_alpha=5):
         raise ValueError("net")
     h, L = int(hid[net]), int(nl[net])
     enc = {NET_MAPPING1: 3, NET_MAPPING2: 3, NET_ATLAS: 4 * pe_atlas, NET_ALPHA: 6 * pe_alpha}[net]
+    if cfg is not None:     # a mapping net with positional encoding reads 2 * 3 * K Fourier features (implicit_neural_networks.py:28-33)
+        if net == NET_MAPPING1 and cfg.use_positional_encoding_mapping1:
+            enc = 6 * int(cfg.number_of_positional_encoding_mapping1)
+        if net == NET_MAPPING2 and cfg.use_positional_encoding_mapping2:
+            enc = 6 * int(cfg.number_of_positional_encoding_mapping2)
     out = {NET_MAPPING1: 2, NET_MAPPING2: 2, NET_ATLAS: 3, NET_ALPHA: 1}[net]
     skips = (4, 7) if net == NET_ATLAS else ()
     dims = []

@@ -26,6 +26,9 @@
 #define AF_TILE_F     (AF_HID * AF_TROWS)       // floats per 256-feature T-layout tile
 #define AF_CHUNK_MAX  65536         // bytes per LDS weight buffer
 #define AF_MAX_LAYERS 8
+// kernel kind of a net = its af_net id, except a mapping net WITH positional encoding (use_positional_encoding_mapping*): the alpha
+// net's input stage (PE 3 -> 6K, K <= 5 frequencies in the 5-frequency slot layout, unused slots meet zero weights) with 2 outputs
+#define AF_KIND_MAP_PE 4
 #define AF_MAX_NETS   4
 #define AF_REC_F      16            // floats per pixel record (64 B)
 #define AF_LOSS_W     16            // floats per loss record: 14 partial sums + #valid fwd + #valid bwd

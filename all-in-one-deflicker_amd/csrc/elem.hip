@@ -551,8 +551,10 @@ __global__ void k_pre_prep(PrePrepArgs a) {
   const float xc = (float)x / a.half_main - 1.f, yc = (float)y / a.half_main - 1.f;
   f32x4 v = {xc, yc, a.t, 0.f};
   *(f32x4*)(a.coords + (size_t)n * 4) = v;
-  float* tl = a.x0_tile + ((size_t)n >> 5) * 1024 + (n & 31);
-  tl[0] = xc; tl[32] = yc; tl[64] = a.t;
+  if (a.x0_tile) {      // the T-layout copy feeds the layer-0 dW of a net that reads xyt directly; a mapping net with PE stores its own PE tile
+    float* tl = a.x0_tile + ((size_t)n >> 5) * 1024 + (n & 31);
+    tl[0] = xc; tl[32] = yc; tl[64] = a.t;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_pre_loss(PreLossArgs a) {

@@ -50,6 +50,7 @@ namespace {
 thread_local std::string g_create_error;     // handle-less errors (af_create, the input-builder utilities): per calling thread
 
 struct NetDesc {
+  int kern = -1;                                        // kernel kind (af_dev.h): the net id, or AF_KIND_MAP_PE for a mapping net with positional encoding
   int id = -1, NL = 0, in_kind = 0, in_feat0 = 0, out = 0, pe_feats = 0, pe_kind = 0;
   unsigned skip = 0; bool dx0 = false; bool used = false;
   int in_feat[AF_MAX_LAYERS], out_feat[AF_MAX_LAYERS];
@@ -140,7 +141,7 @@ enum { T_PREP = 0, T_FWD_1 = 1, T_FWD_2 = 2, T_LOSS = 3, T_BWD_1 = 4, T_BWD_2 = 
 template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
 void describe_net(NetDesc& n, int id, int NL, int in_kind, int pe_freqs, int out, unsigned skip, bool dx0) {
-  n.id = id; n.NL = NL; n.in_kind = in_kind; n.out = out; n.skip = skip; n.dx0 = dx0; n.used = true;
+  n.id = id; n.kern = (in_kind == AF_IN_PE3 && out == 2) ? AF_KIND_MAP_PE : id; n.NL = NL; n.in_kind = in_kind; n.out = out; n.skip = skip; n.dx0 = dx0; n.used = true;
   const int in_dim = in_kind == AF_IN_PE2 ? 2 : 3;
   n.pe_feats = in_kind == AF_IN_XYT ? 0 : 2 * in_dim * pe_freqs;
   n.pe_kind = in_kind == AF_IN_PE3 ? 2 : (in_kind == AF_IN_PE2 ? 1 : 0);
@@ -161,7 +162,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cursor) {
   n.f_base = f_cursor; n.b_base = b_cursor; n.bias_base = bias_cursor;
   bias_cursor += (size_t)n.NL * AF_HID;
-  const int peg = (n.pe_feats + 7) / 8;
+  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.pe_feats + 7) / 8;     // k-groups of 8 PE slots the kernels walk: the 3-D encoding always has its five-frequency slot layout (fewer frequencies leave slots with zero weights)
   size_t foff = 0;   // bytes relative to f_base
   for (int l = 0; l < n.NL; ++l) {
     const bool last = l == n.NL - 1;
@@ -196,9 +197,9 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
 // Streams of the bf16x6 chains: fp32 blocks for layer 0, the skip columns and the output layers, eight 48 KB bf16x3 chunks
 // per 256x256 hidden product, in consumption order (mlpbf.hip).  Returns false if the sizes disagree with the kernels'.
 bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
-  const int peg = (n.pe_feats + 7) / 8;
-  const int cb_l0 = af_mlp_chunk_bytes_bf(n.id, 0, n.NL), cb_hid = af_mlp_chunk_bytes_bf(n.id, 1, n.NL), cb_skip = af_mlp_chunk_bytes_bf(n.id, 2, n.NL);
-  const int cb_last = af_mlp_chunk_bytes_bf(n.id, 3, n.NL), cb_blast = af_mlp_chunk_bytes_bf(n.id, 4, n.NL), cb_bl0h = af_mlp_chunk_bytes_bf(n.id, 5, n.NL);
+  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.pe_feats + 7) / 8;     // k-groups of 8 PE slots the kernels walk: the 3-D encoding always has its five-frequency slot layout (fewer frequencies leave slots with zero weights)
+  const int cb_l0 = af_mlp_chunk_bytes_bf(n.kern, 0, n.NL), cb_hid = af_mlp_chunk_bytes_bf(n.kern, 1, n.NL), cb_skip = af_mlp_chunk_bytes_bf(n.kern, 2, n.NL);
+  const int cb_last = af_mlp_chunk_bytes_bf(n.kern, 3, n.NL), cb_blast = af_mlp_chunk_bytes_bf(n.kern, 4, n.NL), cb_bl0h = af_mlp_chunk_bytes_bf(n.kern, 5, n.NL);
   for (int l = 0; l < AF_MAX_LAYERS; ++l) n.sf_hid[l] = n.sf_fp[l] = n.sb_hid[l] = n.sb_fp[l] = -1;
   n.sf_base = f_cursor; n.sb_base = b_cursor;
   size_t off = 0;
@@ -222,12 +223,12 @@ bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
 // be exactly that sequence, contiguous.
 bool check_chunk_plan(const NetDesc& n) {
   std::vector<int> f, b;
-  f.push_back(af_mlp_chunk_bytes(n.id, 0, n.NL));
-  for (int l = 1; l < n.NL - 1; ++l) { for (int c = 0; c < 4; ++c) f.push_back(af_mlp_chunk_bytes(n.id, 1, n.NL)); if ((n.skip >> l) & 1) f.push_back(af_mlp_chunk_bytes(n.id, 2, n.NL)); }
-  f.push_back(af_mlp_chunk_bytes(n.id, 3, n.NL));
-  b.push_back(af_mlp_chunk_bytes(n.id, 4, n.NL));
-  for (int l = n.NL - 2; l >= 1; --l) for (int c = 0; c < 4; ++c) b.push_back(af_mlp_chunk_bytes(n.id, 1, n.NL));
-  if (n.dx0) b.push_back(af_mlp_chunk_bytes(n.id, 5, n.NL));
+  f.push_back(af_mlp_chunk_bytes(n.kern, 0, n.NL));
+  for (int l = 1; l < n.NL - 1; ++l) { for (int c = 0; c < 4; ++c) f.push_back(af_mlp_chunk_bytes(n.kern, 1, n.NL)); if ((n.skip >> l) & 1) f.push_back(af_mlp_chunk_bytes(n.kern, 2, n.NL)); }
+  f.push_back(af_mlp_chunk_bytes(n.kern, 3, n.NL));
+  b.push_back(af_mlp_chunk_bytes(n.kern, 4, n.NL));
+  for (int l = n.NL - 2; l >= 1; --l) for (int c = 0; c < 4; ++c) b.push_back(af_mlp_chunk_bytes(n.kern, 1, n.NL));
+  if (n.dx0) b.push_back(af_mlp_chunk_bytes(n.kern, 5, n.NL));
   auto same = [](const std::vector<AfChunk>& plan, const std::vector<int>& want) {
     if (plan.size() != want.size()) return false;
     uint32_t off = 0;
@@ -491,7 +492,7 @@ int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool
   MultiFwd m{}; double fl = 0;
   for (const FwdPart& p : parts) {
     if (p.a.NT <= p.a.tile0) continue;
-    m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
+    m.net[m.n] = h->nets[p.net].kern; m.a[m.n] = p.a; ++m.n;
     fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_fwd[p.net];
   }
   if (m.n == 0) return 0;
@@ -504,7 +505,7 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   MultiBwd m{}; double fl = 0;
   for (const BwdPart& p : parts) {
     if (p.a.NT <= p.a.tile0) continue;
-    m.net[m.n] = p.net; m.a[m.n] = p.a; ++m.n;
+    m.net[m.n] = h->nets[p.net].kern; m.a[m.n] = p.a; ++m.n;
     fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_dx[p.net];
   }
   if (m.n == 0) return 0;
@@ -758,7 +759,8 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   auto layers_ok = [](int n) { return n >= 2 && n <= AF_MAX_LAYERS; };
   if (!layers_ok(cfg->number_of_layers_mapping1) || !layers_ok(cfg->number_of_layers_atlas)) return bad("number_of_layers_mapping1 / number_of_layers_atlas must be 2..8");
   if (cfg->positional_encoding_num_atlas != 10) return bad("positional_encoding_num_atlas must be 10");
-  if (cfg->use_positional_encoding_mapping1) return bad("use_positional_encoding_mapping1=true is not built");
+  auto pe_ok = [](int k) { return k >= 1 && k <= 5; };
+  if (cfg->use_positional_encoding_mapping1 && !pe_ok(cfg->number_of_positional_encoding_mapping1)) return bad("number_of_positional_encoding_mapping1 must be 1..5 when use_positional_encoding_mapping1 is set");
   if (!cfg->use_gradient_loss) return bad("use_gradient_loss=false is not built");
   if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
   const bool seg = cfg->two_layer != 0;
@@ -766,7 +768,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
     if (cfg->number_of_channels_mapping2 != AF_HID || cfg->number_of_channels_alpha != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:21,26)");
     if (!layers_ok(cfg->number_of_layers_mapping2) || !layers_ok(cfg->number_of_layers_alpha)) return bad("number_of_layers_mapping2 / number_of_layers_alpha must be 2..8");
     if (cfg->positional_encoding_num_alpha != 5) return bad("positional_encoding_num_alpha must be 5");
-    if (cfg->use_positional_encoding_mapping2) return bad("use_positional_encoding_mapping2=true is not built");
+    if (cfg->use_positional_encoding_mapping2 && !pe_ok(cfg->number_of_positional_encoding_mapping2)) return bad("number_of_positional_encoding_mapping2 must be 1..5 when use_positional_encoding_mapping2 is set");
     if (cfg->global_rigidity_derivative_amount_bg <= 0) return bad("global_rigidity_derivative_amount_bg");
   }
   hipError_t e = hipSetDevice(device_ordinal);
@@ -790,10 +792,13 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   // layers it has (implicit_neural_networks.py:40-44: `if i in skip_layers` for i < num_layers, the output layer included)
   const int nl_atlas = cfg->number_of_layers_atlas;
   const unsigned atlas_skip = (nl_atlas > 4 ? (1u << 4) : 0u) | (nl_atlas > 7 ? (1u << 7) : 0u);
-  describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false);
+  // a mapping net with positional encoding (IMLP(use_positional=True, positional_dim=K), implicit_neural_networks.py:9-13,28-33): PE 3 -> 6K
+  if (cfg->use_positional_encoding_mapping1) describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_PE3, cfg->number_of_positional_encoding_mapping1, 2, 0u, false);
+  else describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false);
   describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, 10, 3, atlas_skip, true);
   if (seg) {
-    describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false);
+    if (cfg->use_positional_encoding_mapping2) describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_PE3, cfg->number_of_positional_encoding_mapping2, 2, 0u, false);
+    else describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false);
     describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, 5, 1, 0u, false);
   }
   for (NetDesc& n : h->nets) if (n.used) {
@@ -1065,11 +1070,11 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       // 16-row chains (mlp16.hip): the batch is smaller than one round of the chip, so a step is bound by the latency
       // of one tile chain — half the rows per wave, half the latency
       { Timer t(h, T_FWD_1, (double)NB * h->flop_fwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
-        if (af_launch_fwd16(net, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
+        if (af_launch_fwd16(M.kern, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
       { Timer t(h, T_BWD_2, (double)NB * h->flop_dx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
-        if (af_launch_bwd16(net, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
+        if (af_launch_bwd16(M.kern, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
       rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * h->flop_fwd[net], false);
     }
   hipError_t e = hipStreamSynchronize(h->stream);

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi(MultiFwd m) {
     case AF_NET_MAP1:  mlp_fwd_body<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
     case AF_NET_MAP2:  mlp_fwd_body<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
     case AF_NET_ATLAS: mlp_fwd_body<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: mlp_fwd_body<NsMapPe, TRAIN>(m.a[s], wg - base, smem); break;
     default:           mlp_fwd_body<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
   }
 }
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi(MultiBwd m) {
     case AF_NET_MAP1:  mlp_bwd_body<NsMap1>(m.a[s], wg - base, smem); break;
     case AF_NET_MAP2:  mlp_bwd_body<NsMap2>(m.a[s], wg - base, smem); break;
     case AF_NET_ATLAS: mlp_bwd_body<NsAtlas>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: mlp_bwd_body<NsMapPe>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body<NsAlpha>(m.a[s], wg - base, smem); break;
   }
 }
@@ -340,6 +342,7 @@ extern "C" int af_mlp_chunk_bytes(int net, int which, int nl) {     // nl: layer
     case AF_NET_MAP2:  return pick(NsMap2{});
     case AF_NET_ATLAS: return pick(NsAtlas{});
     case AF_NET_ALPHA: return pick(NsAlpha{});
+    case AF_KIND_MAP_PE: return pick(NsMapPe{});
     default: return -1;
   }
 }

@@ -12,7 +12,9 @@
 // 4 groups of 16 k-values.  Activation / gradient tiles, dz_last and x0 tiles are the usual 32-row T-layout tiles (a
 // 16-row tile fills one half), so k_dw and k_adam are unchanged.  The ReLU sign masks are private to this pair of
 // kernels: 64 bits per lane and layer, element e = 4T + r at bit 31 - (e & 31) of word e >> 5.
-// Mapping nets only (xyt input, no positional encoding, no skips): the nets pre_train_mapping touches.
+// Mapping nets only (no skips): the nets pre_train_mapping touches — xyt input, or (use_positional_encoding_mapping*) the PE 3 -> 6K
+// input stage in the slot order of the 32-row kernels: image slot 8g + 4h + p of lane half h there is k = 16G + 4q + r here with
+// g = 2G + (q >> 1), h = q & 1, so lane quad q computes the features of lane half q & 1 and feeds the halves (q >> 1) of them.
 #include "mlp_common.h"
 
 // acc[T] += A * b over NG groups of 16 k-values.  a_lds includes the lane offset (q*MPAD + j)*16.  Each group runs in
@@ -72,7 +74,7 @@ struct TileStore16 {
 
 template <class NS>
 __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
-  static_assert(NS::IN == AF_IN_XYT && NS::SKIP == 0, "mapping nets only");
+  static_assert((NS::IN == AF_IN_XYT || NS::IN == AF_IN_PE3) && NS::SKIP == 0, "mapping nets only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CB = ChunkBytes<NS>;
   const int tid = threadIdx.x;
@@ -89,11 +91,39 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
   const int nl = a.nl;
   stage_bias(nl, a.bias, smem + AF_BIAS_LDS, tid);
 
-  float x0[4];
+  constexpr int NG0 = NS::IN == AF_IN_XYT ? 1 : 2;              // groups of 16 k-values of the first layer
+  float x0[4 * NG0];
   {
     const f32x4 v = *(const f32x4*)(a.in + (size_t)row * 4);
+    if constexpr (NS::IN == AF_IN_XYT) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) x0[p] = (q == 0 && p < 3) ? v[p] : 0.f;     // k = 4q + p; only k < 3 is real
+      for (int p = 0; p < 4; ++p) x0[p] = (q == 0 && p < 3) ? v[p] : 0.f;     // k = 4q + p; only k < 3 is real
+    } else {      // PE 3 -> 30 slots exactly as mlp.hip computes them for lane half hq (implicit_neural_networks.py:9-13, accurate sinf / cosf)
+      const int hq = q & 1;
+      const float x[3] = {v[0], v[1], v[2]};
+      const float bA = __builtin_ldexpf(3.14159265358979323846f, 2 * hq), bB = __builtin_ldexpf(3.14159265358979323846f, 2 * hq + 1);
+      const float b4 = __builtin_ldexpf(3.14159265358979323846f, 4);
+      float pe[16];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        pe[d] = sinf(x[d] * bA); pe[3 + d] = cosf(x[d] * bA);
+        pe[6 + d] = sinf(x[d] * bB); pe[9 + d] = cosf(x[d] * bB);
+        pe[12 + d] = hq ? cosf(x[d] * b4) : sinf(x[d] * b4);
+      }
+      pe[15] = 0.f;
+      if (live && a.pe_tile && (q >> 1) == 0) {   // PE features in reference feature order, T-layout [64][32], for the layer-0 dW
+        const auto r = af_rsrc_uniform(a.pe_tile + (size_t)tile * 64 * 32, 64 * 32 * 4);
+#pragma unroll
+        for (int rho = 0; rho < 15; ++rho) {
+          if (rho < 12) af_bs32(pe[rho], r, (12 * hq * 32 + roff) * 4, rho * 128);
+          else          af_bs32(pe[rho], r, (3 * hq * 32 + roff) * 4, (24 + rho - 12) * 128);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) x0[4 * g + pp] = (q >> 1) ? pe[8 * g + 4 + pp] : pe[8 * g + pp];
+    }
   }
   const int a_off = (q * 256 + j) * 16;
   const int voff_t = (4 * q * 32 + roff) * 4;
@@ -123,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
 
   // ---- layer 0: one group of 16 k-values, of which k < 3 carry data.  Slots 2, 3 of that group lie past the 8 KB
   // image (the stage always copies 64 KB: they hold the next layer's weights, finite) and meet B = 0.
-  { const char* buf = cs.next<CB::L0>(); init_bias(0); mm16<16, 256, 1, 0, 4>(acc, x0, buf + a_off, hook_dma); }
+  { const char* buf = cs.next<CB::L0>(); init_bias(0); mm16<16, 256, NG0, 0, 4>(acc, x0, buf + a_off, hook_dma); }
   relu_out(0);
 
   for (int l = 1; l <= nl - 2; ++l) {
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
 
 template <class NS>
 __global__ __launch_bounds__(256, 1) void k_mlp16_bwd(BwdArgs a) {
-  static_assert(NS::IN == AF_IN_XYT && NS::SKIP == 0 && !NS::DX0, "mapping nets only");
+  static_assert((NS::IN == AF_IN_XYT || NS::IN == AF_IN_PE3) && NS::SKIP == 0 && !NS::DX0, "mapping nets only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CB = ChunkBytes<NS>;
   const int tid = threadIdx.x;
@@ -232,6 +262,7 @@ extern "C" int af_launch_fwd16(int net, const FwdArgs* a, hipStream_t s) {
   switch (net) {
     case AF_NET_MAP1: hipLaunchKernelGGL((k_mlp16_fwd<NsMap1>), grid, block, AF_LDS_BYTES, s, *a); break;
     case AF_NET_MAP2: hipLaunchKernelGGL((k_mlp16_fwd<NsMap2>), grid, block, AF_LDS_BYTES, s, *a); break;
+    case AF_KIND_MAP_PE: hipLaunchKernelGGL((k_mlp16_fwd<NsMapPe>), grid, block, AF_LDS_BYTES, s, *a); break;
     default: return -1;
   }
   return (int)hipGetLastError();
@@ -241,6 +272,7 @@ extern "C" int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s) {
   switch (net) {
     case AF_NET_MAP1: hipLaunchKernelGGL((k_mlp16_bwd<NsMap1>), grid, block, AF_LDS_BYTES, s, *a); break;
     case AF_NET_MAP2: hipLaunchKernelGGL((k_mlp16_bwd<NsMap2>), grid, block, AF_LDS_BYTES, s, *a); break;
+    case AF_KIND_MAP_PE: hipLaunchKernelGGL((k_mlp16_bwd<NsMapPe>), grid, block, AF_LDS_BYTES, s, *a); break;
     default: return -1;
   }
   return (int)hipGetLastError();
@@ -248,7 +280,7 @@ extern "C" int af_launch_bwd16(int net, const BwdArgs* a, hipStream_t s) {
 extern "C" int af_mlp16_init() {
   hipError_t e = hipSuccess;
 #define AF_ATTR(K) do { hipError_t r = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES); if (r != hipSuccess) e = r; } while (0)
-  AF_ATTR((k_mlp16_fwd<NsMap1>)); AF_ATTR((k_mlp16_fwd<NsMap2>)); AF_ATTR((k_mlp16_bwd<NsMap1>)); AF_ATTR((k_mlp16_bwd<NsMap2>));
+  AF_ATTR((k_mlp16_fwd<NsMap1>)); AF_ATTR((k_mlp16_fwd<NsMap2>)); AF_ATTR((k_mlp16_bwd<NsMap1>)); AF_ATTR((k_mlp16_bwd<NsMap2>)); AF_ATTR((k_mlp16_fwd<NsMapPe>)); AF_ATTR((k_mlp16_bwd<NsMapPe>));
 #undef AF_ATTR
   return (int)e;
 }

@@ -14,6 +14,7 @@
 struct NsMap1  { static constexpr int NL = 6, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsMap2  { static constexpr int NL = 4, IN = AF_IN_XYT, K0G = 1, PEG = 0, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsAtlas { static constexpr int NL = 8, IN = AF_IN_PE2, K0G = 5, PEG = 5, OUT = 3; static constexpr unsigned SKIP = (1u << 4) | (1u << 7);   static constexpr bool DX0 = true;  };
+struct NsMapPe { static constexpr int NL = 6, IN = AF_IN_PE3, K0G = 4, PEG = 4, OUT = 2; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 struct NsAlpha { static constexpr int NL = 8, IN = AF_IN_PE3, K0G = 4, PEG = 4, OUT = 1; static constexpr unsigned SKIP = 0;                       static constexpr bool DX0 = false; };
 
 // Byte sizes of the weight chunks, in stream order (host.hip plan_images lays the images out contiguously in

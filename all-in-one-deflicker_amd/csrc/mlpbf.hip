@@ -609,6 +609,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
     case AF_NET_MAP1:  mlp_fwd_body_bf<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
     case AF_NET_MAP2:  mlp_fwd_body_bf<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
     case AF_NET_ATLAS: mlp_fwd_body_bf<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: mlp_fwd_body_bf<NsMapPe, TRAIN>(m.a[s], wg - base, smem); break;
     default:           mlp_fwd_body_bf<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
   }
   AF_CLK_MARK(1);
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
     case AF_NET_MAP1:  mlp_bwd_body_bf<NsMap1>(m.a[s], wg - base, smem); break;
     case AF_NET_MAP2:  mlp_bwd_body_bf<NsMap2>(m.a[s], wg - base, smem); break;
     case AF_NET_ATLAS: mlp_bwd_body_bf<NsAtlas>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: mlp_bwd_body_bf<NsMapPe>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body_bf<NsAlpha>(m.a[s], wg - base, smem); break;
   }
   AF_CLK_MARK(1);
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf3(MultiBwd m) {
     case AF_NET_MAP1:  mlp_bwd_body_bf<NsMap1, 3>(m.a[s], wg - base, smem); break;
     case AF_NET_MAP2:  mlp_bwd_body_bf<NsMap2, 3>(m.a[s], wg - base, smem); break;
     case AF_NET_ATLAS: mlp_bwd_body_bf<NsAtlas, 3>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: mlp_bwd_body_bf<NsMapPe, 3>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body_bf<NsAlpha, 3>(m.a[s], wg - base, smem); break;
   }
 }
@@ -672,6 +675,7 @@ extern "C" int af_mlp_chunk_bytes_bf(int net, int which, int nl) {     // nl: la
     case AF_NET_MAP2:  return pick(NsMap2{});
     case AF_NET_ATLAS: return pick(NsAtlas{});
     case AF_NET_ALPHA: return pick(NsAlpha{});
+    case AF_KIND_MAP_PE: return pick(NsMapPe{});
     default: return -1;
   }
 }

@@ -31,7 +31,7 @@ typedef struct af_config {
   int32_t number_of_channels_mapping1, number_of_layers_mapping1;   /* config :24-25  (256, 6) */
   int32_t number_of_channels_atlas, number_of_layers_atlas;         /* config :19-20  (256, 8) */
   int32_t positional_encoding_num_atlas;         /* config :31 (10) */
-  int32_t use_positional_encoding_mapping1;      /* config :32 (false; true is not built) */
+  int32_t use_positional_encoding_mapping1;      /* config :32 (false) */
   int32_t derivative_amount;                     /* config :10 */
   int32_t include_global_rigidity_loss;          /* config :39 */
   int32_t global_rigidity_derivative_amount_fg;  /* config :40 */
@@ -47,12 +47,14 @@ typedef struct af_config {
   int32_t number_of_channels_mapping2, number_of_layers_mapping2;   /* config :26-27  (256, 4) */
   int32_t number_of_channels_alpha, number_of_layers_alpha;         /* config :21-22  (256, 8) */
   int32_t positional_encoding_num_alpha;         /* config :18 (5) */
-  int32_t use_positional_encoding_mapping2;      /* config :34 (false; true is not built) */
+  int32_t use_positional_encoding_mapping2;      /* config :34 (false) */
   int32_t global_rigidity_derivative_amount_bg;  /* config :41 */
   int32_t stop_bootstrapping_iteration;          /* config :23 */
   float global_rigidity_coeff_bg;                /* config :43 */
   float alpha_bootstrapping_factor, alpha_flow_factor, sparsity_coeff;   /* config :16,17,30 */
-  int32_t reserved[4];
+  int32_t number_of_positional_encoding_mapping1;   /* config :33 (4): frequencies K of mapping1's PE (3 -> 6K), 1..5, read when use_positional_encoding_mapping1 */
+  int32_t number_of_positional_encoding_mapping2;   /* config :35 (2): the same for mapping2 */
+  int32_t reserved[2];
 } af_config;
 
 /* Replaces model construction + optimizer construction (stage1_neural_atlas.py:112-134).  Parameters

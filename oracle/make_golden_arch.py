@@ -26,8 +26,12 @@ from src.models.stage_1.implicit_neural_networks import IMLP      # noqa: E402
 from oracle import atlas_oracle as O                                # noqa: E402
 
 # kind -> (input_dim, output_dim, use_positional, positional_dim, skip_layers)      (the constructor calls of the two stage-1 scripts)
-KINDS = {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "alpha": (3, 1, True, 5, [])}
-VARIANTS = [("mapping", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("atlas", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("alpha", n) for n in (2, 3, 5, 8)]
+KINDS = {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "alpha": (3, 1, True, 5, []),
+         # mapping nets WITH positional encoding (use_positional_encoding_mapping*, number_of_positional_encoding_mapping* = K): PE 3 -> 6K
+         "mappingpe1": (3, 2, True, 1, []), "mappingpe2": (3, 2, True, 2, []), "mappingpe3": (3, 2, True, 3, []),
+         "mappingpe4": (3, 2, True, 4, []), "mappingpe5": (3, 2, True, 5, [])}
+VARIANTS = [("mapping", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("atlas", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("alpha", n) for n in (2, 3, 5, 8)] \
+    + [("mappingpe1", 4), ("mappingpe2", 4), ("mappingpe3", 5), ("mappingpe4", 6), ("mappingpe4", 3), ("mappingpe5", 2)]
 ROWS = 96
 
 

@@ -1,9 +1,10 @@
 """Architectures other than the shipped one: the config's number_of_layers_* keys (stage1_neural_atlas.py:112-128,
-stage1_neural_atlas_seg.py:127-161; implicit_neural_networks.py:16-60) select 2..8 layers per net — the layer loops of the
+stage1_neural_atlas_seg.py:127-161; implicit_neural_networks.py:16-60) select 2..8 layers per net, use_positional_encoding_mapping* / number_of_positional_encoding_mapping* put a Fourier encoding
+(3 -> 6K, K = 1..5) in front of a mapping net — the layer loops of the
 chains are runtime loops, the atlas net's skip_layers = [4, 7] apply to the layers it has (a skip on the OUTPUT layer when
 num_layers is 5 or 8).  Forward outputs of every variant against a fixture written from the reference's own `IMLP`
 (oracle/make_golden_arch.py -> tests/golden/arch_variants.npz), in both arithmetics of the chains, and complete training steps
-of two non-shipped configurations (single atlas and fg/bg) against the CPU oracle."""
+of non-shipped configurations (other depths, mapping nets with positional encoding; single atlas and fg/bg) against the CPU oracle."""
 import os
 
 import numpy as np
@@ -25,7 +26,7 @@ def _state_dict(seed, shapes):
 
 
 def _variants(g, kind):
-    return [int(v.split("_")[1]) for v in g["variants"] if v.startswith(kind + "_")]
+    return [int(v.split("_")[1]) for v in g["variants"] if v.split("_")[0] == kind]
 
 
 @pytest.mark.parametrize("mlp_mode", [1, 0])
@@ -52,12 +53,32 @@ def test_forward_of_every_layer_count_matches_reference_imlp(mlp_mode):
                 assert err < 5e-6, (name, net, mlp_mode, err)
             finally:
                 af.close()
+    # mapping nets WITH positional encoding (use_positional_encoding_mapping*: PE 3 -> 6K in front of layer 0, K = 1..5 frequencies)
+    for name in [str(v) for v in g["variants"] if str(v).startswith("mappingpe")]:
+        K, nl = int(name.split("_")[0][len("mappingpe"):]), int(name.split("_")[1])
+        for net, which in ((A.NET_MAPPING1, "1"), (A.NET_MAPPING2, "2")):
+            cfg = A.default_config(64, 48, 4, {"use_positional_encoding_mapping" + which: True, "number_of_positional_encoding_mapping" + which: K,
+                                                "number_of_layers_mapping" + which: nl}, two_layer=True)
+            af = aiod_amd.AtlasFit(cfg)
+            try:
+                af.set_mlp_mode(mlp_mode)
+                assert af.param_count(net) == int(g[name + "_nparams"]), (name, af.param_count(net))
+                af.load_state_dict(net, _state_dict(int(g[name + "_seed"]), A.imlp_shapes(net, cfg)))
+                rows = np.zeros((g[name + "_rows"].shape[0], 4), np.float32); rows[:, :3] = g[name + "_rows"]
+                err = float(np.abs(af.debug_forward(net, rows)[:, :2] - g[name + "_out"]).max())
+                worst[(name, net)] = err
+                assert err < 5e-6, (name, net, mlp_mode, err)
+            finally:
+                af.close()
     print("mlp_mode %d: worst forward distance from the reference IMLP over %d variants: %.3g" % (mlp_mode, len(worst), max(worst.values())))
 
 
 @pytest.mark.parametrize("two_layer,layers", [(False, dict(number_of_layers_mapping1=3, number_of_layers_atlas=5)),
                                               (False, dict(number_of_layers_mapping1=8, number_of_layers_atlas=2)),
-                                              (True, dict(number_of_layers_mapping1=4, number_of_layers_mapping2=2, number_of_layers_atlas=6, number_of_layers_alpha=3))])
+                                              (True, dict(number_of_layers_mapping1=4, number_of_layers_mapping2=2, number_of_layers_atlas=6, number_of_layers_alpha=3)),
+                                              (False, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=4)),
+                                              (True, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=3, number_of_layers_mapping1=5,
+                                                          use_positional_encoding_mapping2=True, number_of_positional_encoding_mapping2=2))])
 def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, layers, golden, golden_seg, small_video, small_seg_video):
     """Three Adam steps of the whole loop (forward, loss stack, backward, dW, Adam) on the fixture video with other layer counts:
     every loss term within 1e-3 of the CPU oracle built from the same config, end weights close, pre_train_mapping included."""
@@ -80,10 +101,15 @@ def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, lay
             nets = (A.NET_MAPPING1, A.NET_ATLAS)
         for net, m in zip(nets, models):
             af.load_state_dict(net, m.state_dict())
-        # the 16-row pre-train chains with this depth: a few steps on the device, state copied into the oracle
-        af.pre_train_mapping(1, seed=3)
-        if two_layer:
-            af.pre_train_mapping(1, seed=4, net=A.NET_MAPPING2)
+        # the 16-row pre-train chains with this depth / input stage: the same injected draws on the device and in the oracle's
+        # restatement of pre_train_mapping (unwrap_utils.py:176-198), loss per step compared; then the device state goes into the oracle
+        F = int(gd["nframes"])
+        for pi, net in enumerate(nets[:2] if two_layer else nets[:1]):
+            gen0 = torch.Generator().manual_seed(40 + pi)
+            ys = torch.randint(v.resy, (F, 512), generator=gen0); xs = torch.randint(v.resx, (F, 512), generator=gen0)
+            pl_h = af.pre_train_mapping(1, ys.numpy(), xs.numpy(), net=net, return_losses=True)
+            pl_o = O.pre_train_mapping(models[pi], v.F, cfg["uv_mapping_scale"], v.resx, v.resy, v.larger_dim, 1, ys, xs, batch=512)
+            assert np.allclose(pl_h, np.array(pl_o), rtol=1e-4), (layers, net, pl_h, pl_o)
         for net, m in zip(nets, models):
             flat, off = af.get_params_flat(net), 0
             with torch.no_grad():
