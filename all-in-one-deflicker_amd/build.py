@@ -7,7 +7,25 @@ SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libatlasfit.so")
 UNITS = ["mlp.hip", "mlpbf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
 HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", os.path.join("..", "..", "include", "atlasfit.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("AF_HIPCC_EXTRA", "").split()     # AF_HIPCC_EXTRA: -D switches of the kernel experiments (tools/experiments/README.md); use with --force
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("AF_HIPCC_EXTRA", "").split()     # AF_HIPCC_EXTRA: -D switches of the kernel experiments (tools/experiments/README.md); use with --force
+
+
+def _check_no_scratch(name, stderr):
+    """Every kernel of the library must compile without scratch memory (register spills): the chains run at 256 VGPR + ~240 AGPR by
+    design, and a spill is silent — it shows up as extra HBM traffic only (round 3: a possibly-empty layer loop cost the training
+    forward 86 spilled registers per chain, +12 % HBM writes).  The compiler's kernel-resource-usage remarks are parsed here and a
+    non-zero ScratchSize fails the build loudly."""
+    import re
+    bad, cur = [], None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and int(m.group(1)) != 0:
+            bad.append((cur, int(m.group(1))))
+    if bad and not os.environ.get("AF_ALLOW_SCRATCH"):
+        raise RuntimeError("%s: kernels with scratch (spilled registers): %s" % (name, bad))
 
 
 def _hipcc():
@@ -43,8 +61,9 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr))
-        if verbose and r.stderr.strip():
-            print(r.stderr)
+        _check_no_scratch(name, r.stderr)
+        if verbose and ("warning:" in r.stderr or "error:" in r.stderr):      # the resource-usage remarks alone are not worth printing
+            print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l))
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))

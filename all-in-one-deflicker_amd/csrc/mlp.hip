@@ -15,7 +15,7 @@
 // list of independent (net, row-tile range) parts.
 #include "mlp_common.h"
 
-template <class NS, bool TRAIN>
+template <class NS, bool TRAIN, bool HID>      // HID: see mlp_fwd_body_bf (mlpbf.hip)
 AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +105,9 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
       }
       ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
+    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
   auto hook_dma_store = [&](auto gi) {
@@ -121,7 +124,9 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
   relu_out(0);
 
   // ---- hidden layers 1 .. NL-2
-  for (int l = 1; l <= nl - 2; ++l) {
+  if constexpr (HID) {
+  int l = 1;
+  do {
     init_bias(acc, smem + AF_BIAS_LDS, l, h);
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 0, 4>(acc, in, buf + a_off8, hook_dma_store); }
     { const char* buf = cs.next<CB::HID>(); mm_block<8, 8, 32, 4>(acc, in, buf + a_off8, hook_dma); }
@@ -131,6 +136,7 @@ AF_DEV void mlp_fwd_body(const FwdArgs& a, int wg, char* smem) {
       if ((NS::SKIP >> l) & 1) { const char* buf = cs.next<CB::SKIP>(); mm_block<8, NS::PEG, 0, 4>(acc, pe, buf + a_off8, hook_dma); }
     }
     relu_out(l);
+  } while (++l <= nl - 2);
   }
 
   // ---- output layer (1..3 real outputs), tanh.  A 32-wide MFMA tile would spend 128+ full-rate MFMAs on 2 or 3
@@ -226,6 +232,9 @@ AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
         in[T * 16 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
                                                    (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 1], 31 - ((T & 1) * 16 + r), 1));
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
+    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 8) cs.issue2(); ts.template part<decltype(gi)::value>(in); };
@@ -288,11 +297,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi(MultiFwd m) {
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
   switch (m.net[s]) {
-    case AF_NET_MAP1:  mlp_fwd_body<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_NET_MAP2:  mlp_fwd_body<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_NET_ATLAS: mlp_fwd_body<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_KIND_MAP_PE: mlp_fwd_body<NsMapPe, TRAIN>(m.a[s], wg - base, smem); break;
-    default:           mlp_fwd_body<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP1:  if (m.a[s].nl > 2) mlp_fwd_body<NsMap1, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsMap1, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  if (m.a[s].nl > 2) mlp_fwd_body<NsMap2, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsMap2, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: if (m.a[s].nl > 2) mlp_fwd_body<NsAtlas, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsAtlas, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: if (m.a[s].nl > 2) mlp_fwd_body<NsMapPe, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsMapPe, TRAIN, false>(m.a[s], wg - base, smem); break;
+    default:           if (m.a[s].nl > 2) mlp_fwd_body<NsAlpha, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsAlpha, TRAIN, false>(m.a[s], wg - base, smem); break;
   }
 }
 

@@ -317,7 +317,10 @@ AF_DEV void bf_enter(BfPipe& pp, const float (&in)[128], const char* lane_base) 
   pp.b = bf_split_in(in, 0);
 }
 
-template <class NS, bool TRAIN>
+// HID: the net has hidden 256 -> 256 layers (nl >= 3).  A two-layer net (layer 0 + output layer) takes the copy without the layer
+// loop: with a possibly-empty loop the compiler keeps the pre-loop activations alive ACROSS it for the zero-trip exit (86 registers
+// spilled to scratch per chain, +12 % HBM writes of the training forward, profiles/r3: found by the byte-model guard of bench.py).
+template <class NS, bool TRAIN, bool HID>
 AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,6 +412,9 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
       }
       ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
+    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
 
@@ -422,8 +428,10 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
 
   // ---- hidden layers 1 .. NL-2: eight bf16 chunks each (+ the fp32 block of the skip columns); every iteration runs the
   // same code — what lies behind a layer (its skip block, the next layer's first chunk, the output layer) is only a size
+  if constexpr (HID) {
+  int l = 1;
 #pragma unroll 1
-  for (int l = 1; l <= nl - 2; ++l) {
+  do {
     init_bias(acc, bias_lds, l, h);
     bf_enter(pp, in, lane_base);
     const bool skip = NS::SKIP != 0 && ((NS::SKIP >> l) & 1);
@@ -437,6 +445,7 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
       }
     }
     relu_out(l);
+  } while (++l <= nl - 2);
   }
   lane_base -= lane_off;
 
@@ -535,6 +544,9 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
     const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
     bf_mask_all(in, acc, mk, std::make_integer_sequence<int, 128>{});
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
+    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
@@ -606,11 +618,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
   switch (m.net[s]) {
-    case AF_NET_MAP1:  mlp_fwd_body_bf<NsMap1, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_NET_MAP2:  mlp_fwd_body_bf<NsMap2, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_NET_ATLAS: mlp_fwd_body_bf<NsAtlas, TRAIN>(m.a[s], wg - base, smem); break;
-    case AF_KIND_MAP_PE: mlp_fwd_body_bf<NsMapPe, TRAIN>(m.a[s], wg - base, smem); break;
-    default:           mlp_fwd_body_bf<NsAlpha, TRAIN>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP1:  if (m.a[s].nl > 2) mlp_fwd_body_bf<NsMap1, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body_bf<NsMap1, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_NET_MAP2:  if (m.a[s].nl > 2) mlp_fwd_body_bf<NsMap2, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body_bf<NsMap2, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_NET_ATLAS: if (m.a[s].nl > 2) mlp_fwd_body_bf<NsAtlas, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body_bf<NsAtlas, TRAIN, false>(m.a[s], wg - base, smem); break;
+    case AF_KIND_MAP_PE: if (m.a[s].nl > 2) mlp_fwd_body_bf<NsMapPe, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body_bf<NsMapPe, TRAIN, false>(m.a[s], wg - base, smem); break;
+    default:           if (m.a[s].nl > 2) mlp_fwd_body_bf<NsAlpha, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body_bf<NsAlpha, TRAIN, false>(m.a[s], wg - base, smem); break;
   }
   AF_CLK_MARK(1);
 }

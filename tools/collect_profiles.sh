@@ -9,7 +9,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-# no warm-up, no pre-train: every k_dw / k_mlp_* dispatch in the trace belongs to the 40 timed steps (20 with 9, 20 with 7 row segments)
+# no warm-up, no pre-train: every k_dw / k_mlp_* dispatch in the trace belongs to bench.py's three passes over the same 40 iterations (20 with 9, 20 with
+# 7 row segments): the timed region, the per-kernel pass, and the pass with the opt-in three-product weight-gradient GEMM (k_dw_bf<3>, + 5 warm-up steps)
 BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 0 --pretrain-iters 0"
 run() {  # name, rocprof args..., -- cmd
   local name=$1; shift
