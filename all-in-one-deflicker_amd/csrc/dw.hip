@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const DwSeg* segs = a.segs + (size_t)blockIdx.x * DW_MAXSEG;
-#ifdef DW_CLK      // tools/dwbench.hip: core clock ticks instead of the 100 MHz counter
-  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+#ifdef DW_CLK      // tools/dwbench.hip: core clock ticks AND the 100 MHz counter ([4] per workgroup: ticks0, ticks1, real0, real1)
+  if (a.wg_clock && tid == 0) { a.wg_clock[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); a.wg_clock[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
 #else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
     }
   }
 #ifdef DW_CLK
-  if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+  if (a.wg_clock && tid == 0) { a.wg_clock[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); a.wg_clock[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
 #else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -36,12 +36,16 @@ int main(int argc, char** argv) {
     const double fl = (double)NT * 32 * 2.0 * 256 * 256, by = (double)NT * 2 * AF_TILE_F * 4;
 #ifdef DW_CLK     // core clock ticks each workgroup spent (s_memtime): ticks / event time = the shader clock under this load
     if (mode >= 1) {
-      unsigned long long* clk; CK(hipMalloc(&clk, nwg * 16));
+      unsigned long long* clk; CK(hipMalloc(&clk, nwg * 32));
       DwArgs ac = a; ac.wg_clock = clk;
-      af_launch_dw(&ac, nwg, mode, 0); CK(hipDeviceSynchronize());
-      std::vector<unsigned long long> hc(nwg * 2); CK(hipMemcpy(hc.data(), clk, nwg * 16, hipMemcpyDeviceToHost));
-      double tk = 0; for (int w = 0; w < nwg; ++w) tk += (double)(hc[2 * w + 1] - hc[2 * w]); tk /= nwg;
-      printf("mean ticks per workgroup %.0f = %.0f per stage; over the launch time %.0f MHz\n", tk, tk / (2 * per), tk / (ms * 1000));
+      for (int r = 0; r < 20; ++r) af_launch_dw(&ac, nwg, mode, 0);           // a sustained run: the last launch's stamps are read
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> hc(nwg * 4); CK(hipMemcpy(hc.data(), clk, nwg * 32, hipMemcpyDeviceToHost));
+      double tk = 0, rt = 0, first = 1e30, last = 0;
+      for (int w = 0; w < nwg; ++w) { tk += (double)(hc[4 * w + 1] - hc[4 * w]); rt += (double)(hc[4 * w + 3] - hc[4 * w + 2]); first = std::min(first, (double)hc[4 * w + 2]); last = std::max(last, (double)hc[4 * w + 3]); }
+      tk /= nwg; rt /= nwg;
+      printf("mean ticks per workgroup %.0f = %.0f per stage; ticks / launch time %.0f MHz; ticks / the workgroup's own s_memrealtime span %.0f MHz "
+             "(workgroup span %.1f us mean, first start to last end %.1f us, launch %.1f us)\n", tk, tk / (2 * per), tk / (ms * 1000), tk / (rt / 100.0), rt / 100.0, (last - first) / 100.0, ms * 1000);
     }
 #endif
     printf("DW_ABL=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, cached ? " L2-resident" : "", mode, mode == 2 ? "bf16x3" : (mode ? "bf16x6" : "fp32 MFMA"), per, ms, fl / ms / 1e9, by / ms / 1e9);
