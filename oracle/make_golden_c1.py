@@ -20,9 +20,13 @@ same draws from the seed alone (tests/test_gpu_c1.py) — the fixture only store
                                     seed 0; means over the seeds 25.525 vs 25.647 dB), single frames by up to 2.5 dB:
                                     the reproducibility floor tests/test_gpu_c1.py builds its tolerances on
 
-    tests/golden/c1_reference_fp64_seed2.npz
-                                    seed 2 with `--double`: the same modules, weights and draws in fp64 (25.30 dB, above the
+    tests/golden/c1_reference_fp64_seed2.npz (and _seed0, _seed1)
+                                    `--double`: the same modules, weights and draws in fp64 (seed 2: 25.30 dB, above the
                                     four fp32 runs of that seed, 24.93 .. 25.14): where exact arithmetic lands
+    tests/golden/c1_reference_more.npz
+                                    round 3: further seeds, one reference run each (`--seeds k --threads 3 --out ...` per seed, then
+                                    `--merge`): with the three two-arm seeds the mean over seeds has a standard error <= ~0.1 dB,
+                                    which is what "PSNR within 0.1 dB" needs to be testable at all
 
 Build container only (imports /root/reference read-only; ~17 min of CPU per seed):
 
@@ -111,7 +115,18 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c1_reference.npz"))
     ap.add_argument("--double", action="store_true", help="run the schedule in fp64 from the fp32 initial weights (diagnostic: where exact arithmetic lands)")
+    ap.add_argument("--merge", nargs="+", default=None, help="stack per-seed files written by earlier invocations (same thread count) into --out")
     args = ap.parse_args()
+    if args.merge:
+        parts = [dict(np.load(f)) for f in args.merge]
+        parts.sort(key=lambda d: int(d["seeds"][0]))
+        assert len({int(d["threads"]) for d in parts}) == 1 and len({int(d["iters"]) for d in parts}) == 1
+        out = {k: parts[0][k] for k in ("resx", "resy", "nframes", "iters", "pretrain_iters", "log_every", "threads")}
+        for k in ("seeds", "psnr_pre", "psnr", "psnr_per_frame", "curves", "cpu_seconds", "video_checksum"):
+            out[k] = np.concatenate([d[k] for d in parts], axis=0)
+        np.savez_compressed(args.out, **out)
+        print("merged", [int(x) for x in out["seeds"]], "->", args.out, "PSNR", np.array2string(out["psnr"], precision=3))
+        return
     if args.threads > 0:
         torch.set_num_threads(args.threads)
     c = shipped_config()

@@ -121,3 +121,42 @@ def test_configs0_full_schedule_psnr_within_0p1_db_of_reference():
     assert abs(mh - m_ref) <= tol_mean, (hip, list(g["psnr"]), list(r["psnr"]))
     # different draws (device Philox sampler, not the reference's torch.randint stream): same quality of fit
     assert abs(md - m_ref) <= tol_mean + 0.1, (hip_dev, list(g["psnr"]), list(r["psnr"]))
+
+
+MORE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_reference_more.npz")
+
+
+@pytest.mark.skipif(not (os.path.exists(GOLDEN) and os.path.exists(MORE)), reason="tests/golden/c1_reference_more.npz not generated yet")
+def test_configs0_mean_psnr_over_many_seeds_resolves_0p1_db():
+    """three seeds cannot resolve 0.1 dB when one reference run scatters by 0.23 dB.  With the further seeds of
+    c1_reference_more.npz (one reference run each) the PAIRED difference hip - reference per seed (same video, weights and draws on
+    both sides) averages over n >= 8 seeds to a standard error of ~0.1 dB: BASELINE.md's 0.1 dB is asserted on top of two of those
+    standard errors, and the signed result is printed — a reproducible offset is a finding, not noise.  Seeds 0..2 are
+    compared with the mean of their two reference arms.  fp64 arms of the reference (seeds 0, 1, 2 where present) are printed
+    beside: where exact arithmetic lands."""
+    g = dict(np.load(GOLDEN)); r = dict(np.load(RERUN)); m = dict(np.load(MORE))
+    for k in ("resx", "resy", "nframes", "iters", "pretrain_iters"):
+        assert int(m[k]) == int(g[k]), k
+    ref = {int(s): 0.5 * (float(g["psnr"][i]) + float(r["psnr"][i])) for i, s in enumerate(g["seeds"])}
+    ref.update({int(s): float(m["psnr"][i]) for i, s in enumerate(m["seeds"])})
+    two_arm = {int(s) for s in g["seeds"]}
+    hip = {}
+    for s in sorted(ref):
+        src = g if s in two_arm else m
+        hip[s] = _run(s, src, injected=True)[1]
+    seeds = sorted(ref)
+    d = np.array([hip[s] - ref[s] for s in seeds])
+    n = len(seeds)
+    se = float(d.std(ddof=1) / np.sqrt(n))
+    print("seeds %s" % seeds)
+    print("hip        %s" % np.array2string(np.array([hip[s] for s in seeds]), precision=3))
+    print("reference  %s" % np.array2string(np.array([ref[s] for s in seeds]), precision=3))
+    print("hip - reference per seed %s dB ; mean %+.4f dB, standard error %.4f dB (n = %d), t = %+.2f" % (np.array2string(d, precision=3), d.mean(), se, n, d.mean() / se))
+    for s in (0, 1, 2):
+        f64 = os.path.join(os.path.dirname(GOLDEN), "c1_reference_fp64_seed%d.npz" % s)
+        if os.path.exists(f64) and s in hip:
+            d64 = dict(np.load(f64))
+            print("seed %d: reference in fp64 %.4f dB ; reference fp32 (mean of arms) %.4f ; hip %.4f" % (s, float(d64["psnr"][0]), ref[s], hip[s]))
+    assert n >= 7
+    assert se <= 0.15, se                                   # the comparison resolves what it claims to
+    assert abs(float(d.mean())) <= 0.1 + 2.0 * se, (float(d.mean()), se)
