@@ -608,7 +608,7 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     l.samples = h->samples; l.out_map = M.out_buf; l.out_atlas = A.out_buf; l.dout_map = M.dout; l.dout_atlas = A.dout;
     l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg; l.flow_rank = h->flow_rank; l.live = h->live;
     l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount; l.d_global = c.global_rigidity_derivative_amount_fg;
-    l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
+    l.c_rgb = c.rgb_coeff; l.c_grad = c.use_gradient_loss ? c.gradient_loss_coeff : 0.f; l.c_rig = c.rigidity_coeff;
     l.c_grig = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_flow = c.optical_flow_coeff;
     LCHK(af_launch_loss_single(&l, h->stream));
   }
@@ -673,7 +673,7 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     l.counts = h->counts; l.loss_part = h->loss_part; l.N = N; l.nseg = nseg; l.flow_rank = h->flow_rank; l.live = h->live;
     l.L = (float)L; l.uv_scale = c.uv_mapping_scale; l.d_local = c.derivative_amount;
     l.d_global_fg = c.global_rigidity_derivative_amount_fg; l.d_global_bg = c.global_rigidity_derivative_amount_bg;
-    l.c_rgb = c.rgb_coeff; l.c_grad = c.gradient_loss_coeff; l.c_rig = c.rigidity_coeff;
+    l.c_rgb = c.rgb_coeff; l.c_grad = c.use_gradient_loss ? c.gradient_loss_coeff : 0.f; l.c_rig = c.rigidity_coeff;
     l.c_grig_fg = glob ? c.global_rigidity_coeff_fg : 0.f; l.c_grig_bg = glob ? c.global_rigidity_coeff_bg : 0.f;
     l.c_flow = c.optical_flow_coeff;
     l.c_boot = i > c.stop_bootstrapping_iteration ? 0.f : c.alpha_bootstrapping_factor;     // :193-194
@@ -761,7 +761,6 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (cfg->positional_encoding_num_atlas != 10) return bad("positional_encoding_num_atlas must be 10");
   auto pe_ok = [](int k) { return k >= 1 && k <= 5; };
   if (cfg->use_positional_encoding_mapping1 && !pe_ok(cfg->number_of_positional_encoding_mapping1)) return bad("number_of_positional_encoding_mapping1 must be 1..5 when use_positional_encoding_mapping1 is set");
-  if (!cfg->use_gradient_loss) return bad("use_gradient_loss=false is not built");
   if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
   const bool seg = cfg->two_layer != 0;
   if (seg) {
@@ -1134,7 +1133,7 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
       // mean over an empty set is NaN in the reference (loss_utils.py:317-320)
       if (!h->seg) {
         float* o = losses_out + (size_t)k * 8;
-        o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = glob ? s[3] * invN : 0.f;
+        o[0] = s[0] * invN; o[1] = c.use_gradient_loss ? s[1] * invN : 0.f; o[2] = s[2] * invN; o[3] = glob ? s[3] * invN : 0.f;
         o[4] = 0.5f * (s[5] / nb) + 0.5f * (s[4] / nf);
         o[5] = c.rigidity_coeff * o[2] + (glob ? c.global_rigidity_coeff_fg * o[3] : 0.f) + c.rgb_coeff * o[0] + c.optical_flow_coeff * o[4] + c.gradient_loss_coeff * o[1];
         o[6] = nf; o[7] = nb;
@@ -1142,7 +1141,7 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
       } else {
         float* o = losses_out + (size_t)k * 16;
         const float boot = i > c.stop_bootstrapping_iteration ? 0.f : c.alpha_bootstrapping_factor;
-        o[0] = s[0] * invN; o[1] = s[1] * invN; o[2] = s[2] * invN; o[3] = s[3] * invN;
+        o[0] = s[0] * invN; o[1] = c.use_gradient_loss ? s[1] * invN : 0.f; o[2] = s[2] * invN; o[3] = s[3] * invN;
         o[4] = glob ? s[4] * invN : 0.f; o[5] = glob ? s[5] * invN : 0.f;
         o[6] = 0.5f * (s[7] / nb) + 0.5f * (s[6] / nf);
         o[7] = 0.5f * (s[9] / nb) + 0.5f * (s[8] / nf);

@@ -36,7 +36,7 @@ typedef struct af_config {
   int32_t include_global_rigidity_loss;          /* config :39 */
   int32_t global_rigidity_derivative_amount_fg;  /* config :40 */
   int32_t stop_global_rigidity;                  /* config :44 */
-  int32_t use_gradient_loss;                     /* config :29 (must be true) */
+  int32_t use_gradient_loss;                     /* config :29 (true); false: the gradient term is 0 and carries no gradient (stage1_neural_atlas.py:185-190) */
   float rgb_coeff, gradient_loss_coeff, rigidity_coeff, optical_flow_coeff;   /* config :11,28,12,8 */
   float global_rigidity_coeff_fg;                /* config :42 */
   float uv_mapping_scale;                        /* config :13 */

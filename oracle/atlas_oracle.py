@@ -175,7 +175,10 @@ def loop_body(i, jif, video, mapping, atlas, config):
     uv = mapping(xyt)
     alpha = torch.ones(jif.shape[1], 1)
     rgb = (atlas(uv * 0.5 + 0.5) + 1.0) * 0.5
-    grad_l = gradient_loss_single(video.video_frames_dx, video.video_frames_dy, jif, mapping, atlas, rgb, video.resx, nf)
+    if c.get("use_gradient_loss", True):     # stage1_neural_atlas.py:185-190
+        grad_l = gradient_loss_single(video.video_frames_dx, video.video_frames_dy, jif, mapping, atlas, rgb, video.resx, nf)
+    else:
+        grad_l = torch.zeros(())
     rgb_l = (torch.norm(rgb - rgb_gt, dim=1) ** 2).mean()
     rig_l = rigidity_loss(jif, c["derivative_amount"], L, nf, mapping, uv, c["uv_mapping_scale"])
     glob = c["include_global_rigidity_loss"] and i <= c["stop_global_rigidity"]
@@ -428,7 +431,10 @@ def seg_loop_body(i, jif, video, m1, m2, atlas, model_alpha, config):
     rgb1 = (atlas(uv1 * 0.5 + 0.5) + 1.0) * 0.5
     rgb2 = (atlas(uv2 * 0.5 - 0.5) + 1.0) * 0.5
     rgb = rgb1 * alpha + rgb2 * (1.0 - alpha)
-    grad_l = gradient_loss_seg(video.video_frames_dx, video.video_frames_dy, jif, m1, m2, atlas, rgb, video.resx, nf, model_alpha)
+    if c.get("use_gradient_loss", True):     # stage1_neural_atlas_seg.py:237-242
+        grad_l = gradient_loss_seg(video.video_frames_dx, video.video_frames_dy, jif, m1, m2, atlas, rgb, video.resx, nf, model_alpha)
+    else:
+        grad_l = torch.zeros(())
     rgb_l = (torch.norm(rgb - rgb_gt, dim=1) ** 2).mean()
     sparse_l = (torch.norm(rgb1 * (1.0 - alpha), dim=1) ** 2).mean()
     s = c["uv_mapping_scale"]

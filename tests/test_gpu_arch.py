@@ -77,6 +77,7 @@ def test_forward_of_every_layer_count_matches_reference_imlp(mlp_mode):
                                               (False, dict(number_of_layers_mapping1=8, number_of_layers_atlas=2)),
                                               (True, dict(number_of_layers_mapping1=4, number_of_layers_mapping2=2, number_of_layers_atlas=6, number_of_layers_alpha=3)),
                                               (False, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=4)),
+                                              (False, dict(use_gradient_loss=False)), (True, dict(use_gradient_loss=False)),
                                               (True, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=3, number_of_layers_mapping1=5,
                                                           use_positional_encoding_mapping2=True, number_of_positional_encoding_mapping2=2))])
 def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, layers, golden, golden_seg, small_video, small_seg_video):
