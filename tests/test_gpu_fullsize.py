@@ -256,6 +256,60 @@ def test_full_size_is_bit_reproducible_and_finite(full):
     assert (outs[0][0][:, 6] <= 10000).all() and (outs[0][0][:, 6] > 9000).all()  # ~1/80 of the samples sit on the last frame
 
 
+@pytest.mark.parametrize("two_layer", [False, True])
+def test_long_run_is_bit_reproducible(two_layer):
+    """The chains hand LDS chunks over on a COUNTED vmcnt (tile stores stay in flight behind the DMA pieces they follow) and read
+    their weight fragments through asm the compiler's wait insertion cannot see (mlpbf.hip, round 3): a mistake there would show
+    as a rare, timing-dependent stale tile.  600 consecutive iterations at full size (both row regimes, device sampler) twice from
+    the same state: every loss record and every end weight of every net must be BIT-identical, and a third run under a different
+    co-runner load (a second handle training on the same GPU from another thread) as well."""
+    import threading
+    import aiod_amd
+    import bench
+    dev = torch.device("cuda", 0)
+    resx, resy, F = 768, 432, 80
+    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev)
+    if two_layer:
+        video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=4, device=dev),)
+    sds = bench.init_state_dicts(99, two_layer)
+
+    def handle():
+        h = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=two_layer))
+        h.upload_video(*video)
+        return h
+
+    def run(h):
+        for net in h.nets:
+            h.load_state_dict(net, sds[net])
+            z = np.zeros(h.param_count(net), np.float32)
+            h.set_adam_state(net, z, z, 0)
+        h.pre_train_mapping(1, seed=5)
+        if two_layer:
+            h.pre_train_mapping(1, seed=6, net=aiod_amd.NET_MAPPING2)
+        losses = h.train_steps(4700, 600, None, seed=21)
+        return losses, [h.get_params_flat(net) for net in h.nets]
+    af = handle()
+    a = run(af)
+    b = run(af)
+    other = handle()
+    stop = threading.Event()
+
+    def co_runner():
+        while not stop.is_set():
+            other.train_steps(0, 20, None, seed=3, return_losses=False)
+    t = threading.Thread(target=co_runner); t.start()
+    try:
+        c = run(af)
+    finally:
+        stop.set(); t.join()
+    other.close(); af.close()
+    assert np.isfinite(a[0]).all()
+    for x in (b, c):
+        assert np.array_equal(a[0], x[0])
+        for pa, px in zip(a[1], x[1]):
+            assert np.array_equal(pa, px)
+
+
 def test_render_is_consistent_with_forward_and_psnr_formula(full):
     import aiod_amd
     af, video, sds = full
