@@ -162,7 +162,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cursor) {
   n.f_base = f_cursor; n.b_base = b_cursor; n.bias_base = bias_cursor;
   bias_cursor += (size_t)n.NL * AF_HID;
-  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.pe_feats + 7) / 8;     // k-groups of 8 PE slots the kernels walk: the 3-D encoding always has its five-frequency slot layout (fewer frequencies leave slots with zero weights)
+  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.in_kind == AF_IN_PE2 ? 5 : 0);     // k-groups of 8 PE slots the kernels walk: the encodings always have their shipped slot layout (3-D: five frequencies, 2-D: ten); fewer frequencies leave slots with zero weights
   size_t foff = 0;   // bytes relative to f_base
   for (int l = 0; l < n.NL; ++l) {
     const bool last = l == n.NL - 1;
@@ -197,7 +197,7 @@ void plan_images(NetDesc& n, size_t& f_cursor, size_t& b_cursor, size_t& bias_cu
 // Streams of the bf16x6 chains: fp32 blocks for layer 0, the skip columns and the output layers, eight 48 KB bf16x3 chunks
 // per 256x256 hidden product, in consumption order (mlpbf.hip).  Returns false if the sizes disagree with the kernels'.
 bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
-  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.pe_feats + 7) / 8;     // k-groups of 8 PE slots the kernels walk: the 3-D encoding always has its five-frequency slot layout (fewer frequencies leave slots with zero weights)
+  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.in_kind == AF_IN_PE2 ? 5 : 0);     // k-groups of 8 PE slots the kernels walk: the encodings always have their shipped slot layout (3-D: five frequencies, 2-D: ten); fewer frequencies leave slots with zero weights
   const int cb_l0 = af_mlp_chunk_bytes_bf(n.kern, 0, n.NL), cb_hid = af_mlp_chunk_bytes_bf(n.kern, 1, n.NL), cb_skip = af_mlp_chunk_bytes_bf(n.kern, 2, n.NL);
   const int cb_last = af_mlp_chunk_bytes_bf(n.kern, 3, n.NL), cb_blast = af_mlp_chunk_bytes_bf(n.kern, 4, n.NL), cb_bl0h = af_mlp_chunk_bytes_bf(n.kern, 5, n.NL);
   for (int l = 0; l < AF_MAX_LAYERS; ++l) n.sf_hid[l] = n.sf_fp[l] = n.sb_hid[l] = n.sb_fp[l] = -1;
@@ -758,7 +758,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (cfg->number_of_channels_mapping1 != AF_HID || cfg->number_of_channels_atlas != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:19,24)");
   auto layers_ok = [](int n) { return n >= 2 && n <= AF_MAX_LAYERS; };
   if (!layers_ok(cfg->number_of_layers_mapping1) || !layers_ok(cfg->number_of_layers_atlas)) return bad("number_of_layers_mapping1 / number_of_layers_atlas must be 2..8");
-  if (cfg->positional_encoding_num_atlas != 10) return bad("positional_encoding_num_atlas must be 10");
+  if (cfg->positional_encoding_num_atlas < 1 || cfg->positional_encoding_num_atlas > 10) return bad("positional_encoding_num_atlas must be 1..10");
   auto pe_ok = [](int k) { return k >= 1 && k <= 5; };
   if (cfg->use_positional_encoding_mapping1 && !pe_ok(cfg->number_of_positional_encoding_mapping1)) return bad("number_of_positional_encoding_mapping1 must be 1..5 when use_positional_encoding_mapping1 is set");
   if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
@@ -766,7 +766,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (seg) {
     if (cfg->number_of_channels_mapping2 != AF_HID || cfg->number_of_channels_alpha != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:21,26)");
     if (!layers_ok(cfg->number_of_layers_mapping2) || !layers_ok(cfg->number_of_layers_alpha)) return bad("number_of_layers_mapping2 / number_of_layers_alpha must be 2..8");
-    if (cfg->positional_encoding_num_alpha != 5) return bad("positional_encoding_num_alpha must be 5");
+    if (cfg->positional_encoding_num_alpha < 1 || cfg->positional_encoding_num_alpha > 5) return bad("positional_encoding_num_alpha must be 1..5");
     if (cfg->use_positional_encoding_mapping2 && !pe_ok(cfg->number_of_positional_encoding_mapping2)) return bad("number_of_positional_encoding_mapping2 must be 1..5 when use_positional_encoding_mapping2 is set");
     if (cfg->global_rigidity_derivative_amount_bg <= 0) return bad("global_rigidity_derivative_amount_bg");
   }
@@ -794,11 +794,11 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   // a mapping net with positional encoding (IMLP(use_positional=True, positional_dim=K), implicit_neural_networks.py:9-13,28-33): PE 3 -> 6K
   if (cfg->use_positional_encoding_mapping1) describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_PE3, cfg->number_of_positional_encoding_mapping1, 2, 0u, false);
   else describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false);
-  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, 10, 3, atlas_skip, true);
+  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, cfg->positional_encoding_num_atlas, 3, atlas_skip, true);
   if (seg) {
     if (cfg->use_positional_encoding_mapping2) describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_PE3, cfg->number_of_positional_encoding_mapping2, 2, 0u, false);
     else describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false);
-    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, 5, 1, 0u, false);
+    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, cfg->positional_encoding_num_alpha, 1, 0u, false);
   }
   for (NetDesc& n : h->nets) if (n.used) {
     double f = 0, d = n.dx0 ? (double)n.in_feat0 * AF_HID : 0.0;

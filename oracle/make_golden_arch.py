@@ -29,9 +29,12 @@ from oracle import atlas_oracle as O                                # noqa: E402
 KINDS = {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "alpha": (3, 1, True, 5, []),
          # mapping nets WITH positional encoding (use_positional_encoding_mapping*, number_of_positional_encoding_mapping* = K): PE 3 -> 6K
          "mappingpe1": (3, 2, True, 1, []), "mappingpe2": (3, 2, True, 2, []), "mappingpe3": (3, 2, True, 3, []),
-         "mappingpe4": (3, 2, True, 4, []), "mappingpe5": (3, 2, True, 5, [])}
+         "mappingpe4": (3, 2, True, 4, []), "mappingpe5": (3, 2, True, 5, []),
+         # fewer frequencies than shipped on the atlas / alpha nets (positional_encoding_num_atlas / _alpha)
+         "atlaspe6": (2, 3, True, 6, [4, 7]), "atlaspe1": (2, 3, True, 1, [4, 7]), "alphape3": (3, 1, True, 3, [])}
 VARIANTS = [("mapping", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("atlas", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("alpha", n) for n in (2, 3, 5, 8)] \
-    + [("mappingpe1", 4), ("mappingpe2", 4), ("mappingpe3", 5), ("mappingpe4", 6), ("mappingpe4", 3), ("mappingpe5", 2)]
+    + [("mappingpe1", 4), ("mappingpe2", 4), ("mappingpe3", 5), ("mappingpe4", 6), ("mappingpe4", 3), ("mappingpe5", 2)] \
+    + [("atlaspe6", 8), ("atlaspe1", 5), ("alphape3", 8)]
 ROWS = 96
 
 

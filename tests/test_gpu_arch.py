@@ -70,6 +70,23 @@ def test_forward_of_every_layer_count_matches_reference_imlp(mlp_mode):
                 assert err < 5e-6, (name, net, mlp_mode, err)
             finally:
                 af.close()
+    # fewer frequencies than shipped on the atlas / alpha nets (positional_encoding_num_atlas 1..10, positional_encoding_num_alpha 1..5)
+    for name in [str(v) for v in g["variants"] if str(v).startswith(("atlaspe", "alphape"))]:
+        kind = name[:5]; K, nl = int(name.split("_")[0][7:]), int(name.split("_")[1])
+        net, width = (A.NET_ATLAS, 2) if kind == "atlas" else (A.NET_ALPHA, 3)
+        cfg = A.default_config(64, 48, 4, {"positional_encoding_num_" + kind: K, "number_of_layers_" + kind: nl}, two_layer=True)
+        af = aiod_amd.AtlasFit(cfg)
+        try:
+            af.set_mlp_mode(mlp_mode)
+            assert af.param_count(net) == int(g[name + "_nparams"]), (name, af.param_count(net))
+            af.load_state_dict(net, _state_dict(int(g[name + "_seed"]), A.imlp_shapes(net, cfg)))
+            rows = np.zeros((g[name + "_rows"].shape[0], 4), np.float32); rows[:, :width] = g[name + "_rows"]
+            want = g[name + "_out"]
+            err = float(np.abs(af.debug_forward(net, rows)[:, :want.shape[1]] - want).max())
+            worst[(name, net)] = err
+            assert err < 5e-6, (name, net, mlp_mode, err)
+        finally:
+            af.close()
     print("mlp_mode %d: worst forward distance from the reference IMLP over %d variants: %.3g" % (mlp_mode, len(worst), max(worst.values())))
 
 
@@ -78,6 +95,7 @@ def test_forward_of_every_layer_count_matches_reference_imlp(mlp_mode):
                                               (True, dict(number_of_layers_mapping1=4, number_of_layers_mapping2=2, number_of_layers_atlas=6, number_of_layers_alpha=3)),
                                               (False, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=4)),
                                               (False, dict(use_gradient_loss=False)), (True, dict(use_gradient_loss=False)),
+                                              (False, dict(positional_encoding_num_atlas=6)), (True, dict(positional_encoding_num_atlas=7, positional_encoding_num_alpha=2)),
                                               (True, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=3, number_of_layers_mapping1=5,
                                                           use_positional_encoding_mapping2=True, number_of_positional_encoding_mapping2=2))])
 def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, layers, golden, golden_seg, small_video, small_seg_video):
