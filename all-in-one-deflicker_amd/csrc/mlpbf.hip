@@ -288,6 +288,7 @@ AF_DEV void bf_kstep6(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, cons
   if constexpr ((S & 1) == 1) nxt_lane = cs.template publish<(S < 8 ? NST : 0)>(S == 15 ? after_bytes : AF_SLOT_BF) + lane_off;
   const uint32_t nla = (uint32_t)(size_t)nxt_lane;
   (bf_slot<S, ZI, NST, 24 + I1>(acc, in, pp, fm, fh, fln, bn, st, la, nla, cs, ts), ...);                        // slots 24..47
+  bf_lds_wait();          // the next k-step's W_lo fragments (read in slots 24..27, ~20 MFMAs ago) before anything - a register copy included - touches them
 #pragma unroll
   for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
   pp.b = bn;
