@@ -432,7 +432,7 @@ class AtlasFit:
         return out
 
     def set_dw_mode(self, mode):
-        """k_dw arithmetic: 2 = bf16x3 (two bf16 per operand, three products; default), 1 = bf16x6 (fp32-faithful), 0 = fp32 MFMA."""
+        """k_dw arithmetic: 1 = bf16x6 (fp32-faithful; the default), 2 = bf16x3 (two bf16 per operand, three products: narrower than fp32, opt-in), 0 = fp32 MFMA."""
         self._chk(self.lib.af_set_dw_mode(self.h, int(mode)))
 
     def set_mlp_mode(self, mode):
