@@ -117,3 +117,32 @@ def test_seg_trajectory_matches_reference_fixture(golden_seg, small_seg_video):
     assert np.abs(ends - golden_seg["end_samples"]).max() < 1e-5
     mean, _ = O.mean_psnr_seg(tr.m1, tr.m2, tr.atlas, tr.alpha, small_seg_video)
     assert abs(mean - float(golden_seg["psnr"])) < 1e-3
+
+
+def test_oracle_imlp_matches_reference_fixture_for_every_architecture():
+    """tests/golden/arch_variants.npz (oracle/make_golden_arch.py: forward outputs of the REFERENCE's IMLP for 2..8 layers per net
+    kind, mapping nets with positional encoding, smaller encodings): the restatement rebuilt from the seed reproduces them bit for
+    bit — the CPU pin of the oracle for the architectures tests/test_gpu_arch.py holds the HIP chains against."""
+    import os
+    import torch
+    from oracle import atlas_oracle as O
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arch_variants.npz")))
+    assert len(g["variants"]) >= 27
+
+    def kind_args(kind):       # (input_dim, output_dim, use_positional, positional_dim, skip_layers): the constructor calls of the two stage-1 scripts
+        if kind.startswith("mappingpe"):
+            return 3, 2, True, int(kind[len("mappingpe"):]), []
+        if kind.startswith("atlaspe"):
+            return 2, 3, True, int(kind[len("atlaspe"):]), [4, 7]
+        if kind.startswith("alphape"):
+            return 3, 1, True, int(kind[len("alphape"):]), []
+        return {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "alpha": (3, 1, True, 5, [])}[kind]
+    for name in [str(v) for v in g["variants"]]:
+        kind, nl = name.split("_")[0], int(name.split("_")[1])
+        ind, outd, pos, pdim, skips = kind_args(kind)
+        torch.manual_seed(int(g[name + "_seed"]))
+        m = O.OracleIMLP(ind, outd, 256, pos, pdim, skips, nl)
+        assert sum(p.numel() for p in m.parameters()) == int(g[name + "_nparams"]), name
+        with torch.no_grad():
+            y = m(torch.from_numpy(g[name + "_rows"])).numpy()
+        assert np.array_equal(y, g[name + "_out"]), name
