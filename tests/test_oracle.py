@@ -146,3 +146,29 @@ def test_oracle_imlp_matches_reference_fixture_for_every_architecture():
         with torch.no_grad():
             y = m(torch.from_numpy(g[name + "_rows"])).numpy()
         assert np.array_equal(y, g[name + "_out"]), name
+
+
+def test_complete_schedule_fixtures_describe_the_videos_the_gpu_tests_rebuild():
+    """The configs[0] / configs[4] acceptance fixtures store only results; the GPU tests rebuild the seeded videos and replay the
+    draws.  Here (CPU): the videos the oracle's generators build for the fixtures' seeds have the checksums the reference runs
+    recorded, every run reached a plausible fit, and the configs[4] fixture holds every seed at two thread counts."""
+    import os
+    from oracle import atlas_oracle as O
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for fn in ("c1_reference.npz", "c1_reference_more.npz"):
+        g = dict(np.load(os.path.join(gd, fn)))
+        for k, s in enumerate(g["seeds"]):
+            v = O.synthetic_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=int(s))
+            assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"][k])) < 1e-6, (fn, int(s))
+        assert (g["psnr"] > g["psnr_pre"] + 5.0).all() and (g["curves"][:, -1, 5] < 0.2 * g["curves"][:, 0, 5]).all()
+    g = dict(np.load(os.path.join(gd, "c1_seg_reference.npz")))
+    seeds = sorted({int(s) for s in g["seeds"]})
+    assert len(seeds) >= 3
+    for s in seeds:
+        runs = [i for i in range(len(g["seeds"])) if int(g["seeds"][i]) == s and int(g["double"][i]) == 0]
+        assert len({int(g["threads"][i]) for i in runs}) >= 2, s          # the reference against itself: the tolerance construction needs pairs
+        v = O.synthetic_seg_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=s)
+        for i in runs:
+            assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"][i])) < 1e-6
+            assert abs(float(v.mask_frames.double().sum()) - float(g["mask_checksum"][i])) < 1e-6
+            assert g["psnr"][i] > g["psnr_pre"][i] + 3.0 and g["curves"][i][-1, 11] < 0.2 * g["curves"][i][0, 11]
