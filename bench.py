@@ -39,10 +39,37 @@ KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "
                    "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
 
 
-def synth_video_device(resx, resy, nframes, seed, device):
+def _remap_zero(img, mapx, mapy):
+    """Bilinear sample of img (H, W, C) at (mapx, mapy) with a constant-0 border — what cv2.remap does in unwrap_utils.py:22."""
+    H, W = img.shape[:2]
+    x0, y0 = mapx.floor(), mapy.floor()
+    fx, fy = (mapx - x0)[..., None], (mapy - y0)[..., None]
+
+    def tap(yy, xx):
+        ok = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H))[..., None]
+        return img[yy.clamp(0, H - 1).long(), xx.clamp(0, W - 1).long()] * ok
+
+    return tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) + tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy
+
+
+def _consistent(f12, f21, xx, yy):
+    """unwrap_utils.py:10-23,151-159: a flow vector is valid where ||f12 + warp(f21, f12)|| < 1."""
+    d = f12 + _remap_zero(f21, f12[..., 0] + xx, f12[..., 1] + yy)
+    return ((d[..., 0] ** 2 + d[..., 1] ** 2).sqrt() < 1.0).float()
+
+
+def synth_video_device(resx, resy, nframes, seed, device, flow="constant", flicker=True):
     """Seeded synthetic flickering video generated directly in HBM (same construction as SURVEY.md §8d:
-    translating smooth texture, per-frame gain/gamma flicker, exact flows, reference consistency rule)."""
+    translating smooth texture, per-frame gain/gamma flicker, exact flows, reference consistency rule).
+
+    flow="field": the texture moves by a different similarity transform every frame (rotation, zoom, translation about the frame
+    centre), so the flow differs at every pixel of every frame and nothing is dyadic; each field carries a sub-pixel ripple and a
+    Gaussian error bump a few px high, so the reference's consistency rule leaves holes in the masks, not only border strips
+    (the constant (1.5, 0.5) field cannot see a wrong per-pixel flow gather or a mis-rounded advected coordinate)."""
     import torch
+    if flow == "field":
+        return _synth_video_field_device(resx, resy, nframes, seed, device, flicker)
+    assert flow == "constant" and flicker, flow
     g = torch.Generator(device="cpu").manual_seed(seed)
     nw = 12
     scale = 2 * 3.141592653589793 * 6 / max(resx, resy)
@@ -72,6 +99,65 @@ def synth_video_device(resx, resy, nframes, seed, device):
     mask_rev = torch.zeros_like(mask)
     mask[:, :, :-1] = inb_f[..., None]
     mask_rev[:, :, 1:] = inb_b[..., None]
+    return frames, flows, flows_rev, mask, mask_rev
+
+
+def _synth_video_field_device(resx, resy, nframes, seed, device, flicker=True):
+    import math
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    nw = 12
+    scale = 2 * math.pi * 6 / max(resx, resy)
+    kx = ((torch.rand(nw, 3, generator=g) * 2 - 1) * scale).to(device)
+    ky = ((torch.rand(nw, 3, generator=g) * 2 - 1) * scale).to(device)
+    ph = (torch.rand(nw, 3, generator=g) * 2 * math.pi).to(device)
+    amp = (torch.rand(nw, 3, generator=g) * 0.7 + 0.3).to(device)
+    gain = torch.rand(nframes, generator=g) * 0.4 + 0.8
+    gamma = torch.rand(nframes, generator=g) * 0.2 + 0.9
+    if not flicker:                                            # tests of the generator itself: frame f+1 warped by the flow == frame f
+        gain, gamma = torch.ones(nframes), torch.ones(nframes)
+    n, m = nframes - 1, float(min(resx, resy))
+
+    def uni(lo, hi, *shape):
+        return (torch.rand(*shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).tolist()
+
+    theta, zoom, tx, ty = uni(-0.008, 0.008, n), uni(0.994, 1.006, n), uni(-2.0, 2.0, n), uni(-1.2, 1.2, n)
+    bcx, bcy = uni(0.2 * resx, 0.8 * resx, n, 2), uni(0.2 * resy, 0.8 * resy, n, 2)
+    bax, bay, br = uni(-3.0, 3.0, n, 2), uni(1.5, 3.0, n, 2), uni(0.08 * m, 0.16 * m, n, 2)
+    rk, rp, ra = uni(0.05, 0.4, n, 2), uni(0.0, 6.28, n, 2), uni(0.02, 0.08, n, 2)
+    yy, xx = torch.meshgrid(torch.arange(resy, device=device, dtype=torch.float32),
+                            torch.arange(resx, device=device, dtype=torch.float32), indexing="ij")
+    frames = torch.empty(resy, resx, 3, nframes, device=device)
+    flows = torch.zeros(resy, resx, 2, nframes, device=device)
+    flows_rev = torch.zeros_like(flows)
+    mask = torch.zeros(resy, resx, nframes, device=device)
+    mask_rev = torch.zeros_like(mask)
+    cx, cy = 0.5 * (resx - 1), 0.5 * (resy - 1)
+    inv = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0)                        # frame pixel -> texture coordinate (2x3, row-major); frame 0 = identity
+    for f in range(nframes):
+        xs = (inv[0] * xx + inv[1] * yy + inv[2])[..., None, None]
+        ys = (inv[3] * xx + inv[4] * yy + inv[5])[..., None, None]
+        tex = (amp.T[None, None] * torch.sin(kx.T[None, None] * xs + ky.T[None, None] * ys + ph.T[None, None])).sum(-1)
+        tex = 0.5 + 0.5 * tex / amp.sum(0)
+        frames[:, :, :, f] = (float(gain[f]) * tex.clamp(1e-3, 1.0) ** float(gamma[f])).clamp(0.0, 1.0)
+        if f == n:
+            break
+        co, si = zoom[f] * math.cos(theta[f]), zoom[f] * math.sin(theta[f])
+        a = (co, -si, cx - co * cx + si * cy + tx[f], si, co, cy - si * cx - co * cy + ty[f])            # A_f: frame f -> frame f+1
+        det = a[0] * a[4] - a[1] * a[3]
+        l = (a[4] / det, -a[1] / det, -a[3] / det, a[0] / det)
+        ai = (l[0], l[1], -(l[0] * a[2] + l[1] * a[5]), l[2], l[3], -(l[2] * a[2] + l[3] * a[5]))       # A_f^-1
+        pair = []
+        for j, mm in enumerate((a, ai)):
+            gb = torch.exp(-((xx - bcx[f][j]) ** 2 + (yy - bcy[f][j]) ** 2) / br[f][j] ** 2)
+            rip = ra[f][j] * torch.sin(rk[f][j] * (xx + 0.7 * yy) + rp[f][j])
+            pair.append(torch.stack(((mm[0] - 1.0) * xx + mm[1] * yy + mm[2] + bax[f][j] * gb + rip,
+                                     mm[3] * xx + (mm[4] - 1.0) * yy + mm[5] + bay[f][j] * gb - rip), dim=-1))
+        flows[:, :, :, f], flows_rev[:, :, :, f + 1] = pair[0], pair[1]
+        mask[:, :, f] = _consistent(pair[0], pair[1], xx, yy)
+        mask_rev[:, :, f + 1] = _consistent(pair[1], pair[0], xx, yy)
+        inv = (inv[0] * ai[0] + inv[1] * ai[3], inv[0] * ai[1] + inv[1] * ai[4], inv[0] * ai[2] + inv[1] * ai[5] + inv[2],
+               inv[3] * ai[0] + inv[4] * ai[3], inv[3] * ai[1] + inv[4] * ai[4], inv[3] * ai[2] + inv[4] * ai[5] + inv[5])
     return frames, flows, flows_rev, mask, mask_rev
 
 

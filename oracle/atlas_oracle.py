@@ -304,10 +304,49 @@ def compute_consistency(flow12, flow21):
 
 
 # ------------------------------------------------------------------------------------------------
-def synthetic_video(resx, resy, nframes, seed=0, vx=1.5, vy=0.5):
+def field_motion(rng_uniform, nframes, resx, resy):
+    """Per-frame similarity motion + flow-error bumps of the `flow="field"` videos.  `rng_uniform(lo, hi, n)` draws; the order
+    of the draws is part of the video's definition (bench.synth_video_device feeds a torch generator through the same code)."""
+    n = nframes - 1
+    m = float(min(resx, resy))
+    return dict(theta=rng_uniform(-0.008, 0.008, n), zoom=rng_uniform(0.994, 1.006, n), tx=rng_uniform(-2.0, 2.0, n), ty=rng_uniform(-1.2, 1.2, n),
+                # a Gaussian bump of flow error (like an occlusion the flow network got wrong), one in the forward and one in the backward field
+                bcx=rng_uniform(0.2 * resx, 0.8 * resx, (n, 2)), bcy=rng_uniform(0.2 * resy, 0.8 * resy, (n, 2)),
+                bax=rng_uniform(-3.0, 3.0, (n, 2)), bay=rng_uniform(1.5, 3.0, (n, 2)), br=rng_uniform(0.08 * m, 0.16 * m, (n, 2)),
+                # sub-pixel ripple on both fields (nothing about a real flow field is dyadic)
+                rk=rng_uniform(0.05, 0.4, (n, 2)), rp=rng_uniform(0.0, 6.28, (n, 2)), ra=rng_uniform(0.02, 0.08, (n, 2)))
+
+
+def field_affine(mo, i, resx, resy):
+    """A_i(p) = c + zoom R(theta) (p - c) + t as the 2x3 matrix acting on (x, y, 1), in float64."""
+    cx, cy = 0.5 * (resx - 1), 0.5 * (resy - 1)
+    co, si = float(mo["zoom"][i]) * math.cos(float(mo["theta"][i])), float(mo["zoom"][i]) * math.sin(float(mo["theta"][i]))
+    return np.array([[co, -si, cx - co * cx + si * cy + float(mo["tx"][i])], [si, co, cy - si * cx - co * cy + float(mo["ty"][i])]], np.float64)
+
+
+def affine_inverse(a):
+    l = np.linalg.inv(a[:, :2])
+    return np.concatenate((l, -(l @ a[:, 2:3])), axis=1)
+
+
+def affine_compose(a, b):
+    """a after b."""
+    return np.concatenate((a[:, :2] @ b[:, :2], a[:, :2] @ b[:, 2:3] + a[:, 2:3]), axis=1)
+
+
+def synthetic_video(resx, resy, nframes, seed=0, vx=1.5, vy=0.5, flow="constant", flicker=True):
     """Seeded synthetic flickering video with analytic optical flow: a smooth random texture
     translating (vx, vy) px/frame, per-frame gain U(0.8,1.2) and gamma U(0.9,1.1); forward/backward flows are
-    exact and the consistency masks follow the reference rule (unwrap_utils.py:151-159)."""
+    exact and the consistency masks follow the reference rule (unwrap_utils.py:151-159).
+
+    flow="field" (round 4): the texture moves by a different similarity transform every frame (rotation, zoom, translation about the
+    frame centre), so the flow VARIES PER PIXEL AND PER FRAME and no value is dyadic; each field carries a sub-pixel ripple and a
+    Gaussian bump of error a few px high, so forward and backward fields are mutually consistent to < 1 px only in part of the frame
+    and the masks — the reference's rule, `compute_consistency` — have holes as well as border strips.  This is the video on which a
+    transposed / off-by-one flow gather or a wrongly rounded advected coordinate (loss_utils.py:339-351) shows."""
+    if flow == "field":
+        return _synthetic_video_field(resx, resy, nframes, seed, flicker)
+    assert flow == "constant" and flicker, flow
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:resy, 0:resx].astype(np.float64)
     nwave = 12
@@ -340,6 +379,59 @@ def synthetic_video(resx, resy, nframes, seed=0, vx=1.5, vy=0.5):
         mask_rev[:, :, i + 1, 0] = m21
     t = torch.from_numpy
     return Video(t(frames), t(flows), t(flows_rev), t(mask), t(mask_rev))
+
+
+def _synthetic_video_field(resx, resy, nframes, seed, flicker=True):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:resy, 0:resx].astype(np.float64)
+    nwave = 12
+    kx = rng.uniform(-1, 1, (nwave, 3)) * 2 * np.pi * 6 / max(resx, resy)
+    ky = rng.uniform(-1, 1, (nwave, 3)) * 2 * np.pi * 6 / max(resx, resy)
+    ph = rng.uniform(0, 2 * np.pi, (nwave, 3))
+    amp = rng.uniform(0.3, 1.0, (nwave, 3))
+    gain = rng.uniform(0.8, 1.2, nframes)
+    gamma = rng.uniform(0.9, 1.1, nframes)
+    if not flicker:                                                    # tests of the generator itself: frame f+1 warped by the flow == frame f
+        gain[:], gamma[:] = 1.0, 1.0
+    mo = field_motion(lambda lo, hi, n: rng.uniform(lo, hi, n), nframes, resx, resy)
+    frames = np.zeros((resy, resx, 3, nframes), np.float32)
+    flows = np.zeros((resy, resx, 2, nframes, 1), np.float32)
+    flows_rev = np.zeros_like(flows)
+    mask = np.zeros((resy, resx, nframes, 1), np.float32)
+    mask_rev = np.zeros_like(mask)
+    inv = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])                 # frame pixel -> texture coordinate, frame 0 = identity
+    for f in range(nframes):
+        xs = inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]
+        ys = inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]
+        tex = np.zeros((resy, resx, 3))
+        for w in range(nwave):
+            tex += amp[w] * np.sin(kx[w] * xs[..., None] + ky[w] * ys[..., None] + ph[w])
+        tex = 0.5 + 0.5 * tex / amp.sum(0)
+        frames[:, :, :, f] = np.clip(gain[f] * np.clip(tex, 1e-3, 1.0) ** gamma[f], 0.0, 1.0)
+        if f == nframes - 1:
+            break
+        a = field_affine(mo, f, resx, resy)
+        ai = affine_inverse(a)
+        f12, f21 = field_flow_pair(mo, f, a, ai, xx, yy)
+        flows[:, :, :, f, 0] = f12
+        flows_rev[:, :, :, f + 1, 0] = f21
+        mask[:, :, f, 0] = compute_consistency(f12, f21) < 1.0             # unwrap_utils.py:151-159
+        mask_rev[:, :, f + 1, 0] = compute_consistency(f21, f12) < 1.0
+        inv = affine_compose(inv, ai)
+    t = torch.from_numpy
+    return Video(t(frames), t(flows), t(flows_rev), t(mask), t(mask_rev))
+
+
+def field_flow_pair(mo, i, a, ai, xx, yy):
+    """Forward flow of frame i (A_i p - p) and backward flow of frame i+1 (A_i^-1 p - p), each + ripple + its error bump; float32 (H, W, 2)."""
+    out = []
+    for j, m in enumerate((a, ai)):
+        u = (m[0, 0] - 1.0) * xx + m[0, 1] * yy + m[0, 2]
+        v = m[1, 0] * xx + (m[1, 1] - 1.0) * yy + m[1, 2]
+        g = np.exp(-((xx - float(mo["bcx"][i, j])) ** 2 + (yy - float(mo["bcy"][i, j])) ** 2) / float(mo["br"][i, j]) ** 2)
+        rip = float(mo["ra"][i, j]) * np.sin(float(mo["rk"][i, j]) * (xx + 0.7 * yy) + float(mo["rp"][i, j]))
+        out.append(np.stack((u + float(mo["bax"][i, j]) * g + rip, v + float(mo["bay"][i, j]) * g - rip), axis=-1).astype(np.float32))
+    return out
 
 
 def flat_params(model):
@@ -514,11 +606,11 @@ def mean_psnr_seg(m1, m2, atlas, model_alpha, video):
     return float(np.mean(vals)), vals
 
 
-def synthetic_seg_video(resx, resy, nframes, seed=0):
+def synthetic_seg_video(resx, resy, nframes, seed=0, flow="constant"):
     """synthetic_video + a soft-edged disc moving across the frame as foreground mask (fractional values,
     like the bilinearly-resized masks the reference actually feeds, unwrap_utils.py:68-70) with its own colour
     texture composited over the background."""
-    v = synthetic_video(resx, resy, nframes, seed=seed)
+    v = synthetic_video(resx, resy, nframes, seed=seed, flow=flow)
     rng = np.random.default_rng(seed + 1000)
     yy, xx = np.mgrid[0:resy, 0:resx].astype(np.float64)
     r = 0.22 * min(resx, resy)

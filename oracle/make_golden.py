@@ -73,12 +73,17 @@ def ref_iteration(i, jif_current, v, mapping, atlas, c, device="cpu"):
     return loss, [float(rgb_l), float(grad), float(rig), float(grig) if glob else 0.0, float(flow), float(loss)]
 
 
-def main():
+def main(flow="constant"):
+    """flow="constant": tests/golden/single_small*.npz (the translating video).  flow="field" (round 4): the same networks, pre-train
+    and index stream on the video whose flow differs at every pixel of every frame and whose masks have holes
+    (oracle.atlas_oracle.synthetic_video(flow="field")) -> single_field.npz; the pre-train does not see the video, so the trajectory
+    starts from single_small_start.npz (asserted)."""
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    tag = {"constant": "small", "field": "field"}[flow]
     c = CONFIG
     N = c["samples_batch"]
-    video = O.synthetic_video(RESX, RESY, NF, seed=VSEED)
+    video = O.synthetic_video(RESX, RESY, NF, seed=VSEED, flow=flow)
 
     # ---- 1. networks: reference init == oracle init; forward parity on random rows
     rm, ra = ref_models(WSEED)
@@ -144,7 +149,7 @@ def main():
 
     # ---- 5. portrait aspect (resy > resx): the gradient loss normalises by resx while everything else uses
     # larger_dim = resy (stage1_neural_atlas.py:186-188) — one iteration with and without the global term
-    pv = O.synthetic_video(24, 40, 5, seed=VSEED + 1)
+    pv = O.synthetic_video(24, 40, 5, seed=VSEED + 1, flow=flow)
     prm, pra = ref_models(WSEED + 7)
     pom, poa = O.build_single_atlas_models(c, seed=WSEED + 7)
     ptr = O.SingleAtlasTrainer(c, pv, mapping=pom, atlas=poa)
@@ -160,11 +165,14 @@ def main():
         assert np.allclose(np.array(terms), ora_t, rtol=2e-5, atol=1e-7), (it, terms, ora_t)
         portrait.append(terms)
 
+    if flow != "constant":         # same seeds, same pre-train: the state the loop starts from is the constant-flow fixture's
+        st0 = np.load(os.path.join(out_dir, "single_small_start.npz"))
+        assert np.array_equal(st0["start_map"], start_map) and np.array_equal(st0["start_atlas"], start_atlas)
     if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
-        print("restatement == reference modules (check only, fixtures untouched)")
+        print("restatement == reference modules on the %s-flow video (check only, fixtures untouched)" % flow)
         return
     np.savez_compressed(
-        os.path.join(out_dir, "single_small.npz"),
+        os.path.join(out_dir, "single_%s.npz" % tag),
         resx=RESX, resy=RESY, nframes=NF, video_seed=VSEED, weight_seed=WSEED, samples_batch=N,
         config_keys=np.array(sorted(c.keys())), config_vals=np.array([float(c[k]) for k in sorted(c.keys())]),
         rows_xyt=rows_xyt.numpy(), rows_uv=rows_uv.numpy(), fwd_map=fwd_map.numpy(), fwd_atlas=fwd_atlas.numpy(),
@@ -179,12 +187,16 @@ def main():
         end_map_sample=end_map[::97].copy(), end_atlas_sample=end_atlas[::97].copy(),
         psnr=ref_psnr,
         video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.optical_flows_mask.sum()),
+        flow_checksum=float(video.optical_flows.double().abs().sum() + video.optical_flows_reverse.double().abs().sum()),
+        portrait_losses=np.array(portrait, np.float64),
     )
     # the state the main loop started from (after the reference's pre-train) is needed bit-exactly by the
     # GPU trajectory test: store it in full (fp32, 2.7 MB)
-    np.savez_compressed(os.path.join(out_dir, "single_small_start.npz"), start_map=start_map, start_atlas=start_atlas)
-    print("golden written:", out_dir, "losses[0] =", losses[0], "psnr =", ref_psnr)
+    if flow == "constant":
+        np.savez_compressed(os.path.join(out_dir, "single_small_start.npz"), start_map=start_map, start_atlas=start_atlas)
+    print("golden written:", out_dir, tag, "losses[0] =", losses[0], "psnr =", ref_psnr)
 
 
 if __name__ == "__main__":
-    main()
+    for kind in sys.argv[1:] or ["constant", "field"]:
+        main(kind)

@@ -106,11 +106,14 @@ def ref_seg_iteration(i, jif_current, v, m1, m2, atlas, model_alpha, c, device="
     return loss, [float(t) for t in terms]
 
 
-def main():
+def main(flow="constant"):
+    """flow="field" (round 4): the same four nets, pre-trains and index stream on the video with a per-pixel, per-frame flow field and
+    holed masks -> seg_field.npz, starting from seg_small_start.npz (the pre-train does not see the video; asserted)."""
     out_dir = os.path.join(ROOT, "tests", "golden")
+    tag = {"constant": "small", "field": "field"}[flow]
     c = CONFIG
     N = c["samples_batch"]
-    video = O.synthetic_seg_video(RESX, RESY, NF, seed=VSEED)
+    video = O.synthetic_seg_video(RESX, RESY, NF, seed=VSEED, flow=flow)
 
     # ---- networks: reference init == oracle init, forward parity (mapping2 and alpha are new here)
     rm = ref_models(WSEED)
@@ -181,11 +184,14 @@ def main():
     for e, m in zip(ends, om):
         assert np.allclose(e, O.flat_params(m), atol=2e-6)
     ref_psnr, _ = O.mean_psnr_seg(*rm, video)
+    if flow != "constant":
+        st0 = np.load(os.path.join(out_dir, "seg_small_start.npz"))
+        assert np.array_equal(st0["start_m1"], start_m1) and np.array_equal(st0["start_m2"], start_m2)
     if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
-        print("seg restatement == reference modules (check only, fixtures untouched)")
+        print("seg restatement == reference modules on the %s-flow video (check only, fixtures untouched)" % flow)
         return
     np.savez_compressed(
-        os.path.join(out_dir, "seg_small.npz"),
+        os.path.join(out_dir, "seg_%s.npz" % tag),
         resx=RESX, resy=RESY, nframes=NF, video_seed=VSEED, weight_seed=WSEED, samples_batch=N,
         config_keys=np.array(sorted(c.keys())), config_vals=np.array([float(c[k]) for k in sorted(c.keys())]),
         rows_xyt=rows_xyt.numpy(), fwd_map2=fwd_map2.numpy(), fwd_alpha=fwd_alpha.numpy(),
@@ -194,11 +200,15 @@ def main():
         end_samples=np.concatenate([e[::97] for e in ends]), psnr=ref_psnr,
         video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.mask_frames.double().sum()),
         start_m1_sum=float(np.abs(start_m1).sum()), start_m2_sum=float(np.abs(start_m2).sum()), pre_iters=PRE_ITERS,
+        flow_checksum=float(video.optical_flows.double().abs().sum() + video.optical_flows_reverse.double().abs().sum()),
+        flow_mask_checksum=float(video.optical_flows_mask.sum() + video.optical_flows_reverse_mask.sum()),
     )
     # the pre-trained mapping nets the loop started from, bit-exact (fp32, 1.6 MB)
-    np.savez_compressed(os.path.join(out_dir, "seg_small_start.npz"), start_m1=start_m1, start_m2=start_m2)
-    print("seg golden written; losses[0] =", losses[0], "psnr =", ref_psnr)
+    if flow == "constant":
+        np.savez_compressed(os.path.join(out_dir, "seg_small_start.npz"), start_m1=start_m1, start_m2=start_m2)
+    print("seg golden written (%s); losses[0] =" % tag, losses[0], "psnr =", ref_psnr)
 
 
 if __name__ == "__main__":
-    main()
+    for kind in sys.argv[1:] or ["constant", "field"]:
+        main(kind)

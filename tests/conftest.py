@@ -31,10 +31,9 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
-@pytest.fixture(scope="session")
-def golden():
-    g = dict(np.load(os.path.join(GOLDEN, "single_small.npz"), allow_pickle=False))
-    s = dict(np.load(os.path.join(GOLDEN, "single_small_start.npz")))
+def _load_single(tag):
+    g = dict(np.load(os.path.join(GOLDEN, "single_%s.npz" % tag), allow_pickle=False))
+    s = dict(np.load(os.path.join(GOLDEN, "single_small_start.npz")))       # the pre-train never sees the video: one start state for both videos
     g.update(s)
     g["config"] = {str(k): float(v) for k, v in zip(g["config_keys"], g["config_vals"])}
     for k in ("samples_batch", "derivative_amount", "number_of_channels_atlas", "number_of_layers_atlas",
@@ -44,6 +43,17 @@ def golden():
     for k in ("use_gradient_loss", "use_positional_encoding_mapping1", "include_global_rigidity_loss"):
         g["config"][k] = bool(g["config"][k])
     return g
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return _load_single("small")
+
+
+@pytest.fixture(scope="session")
+def golden_field():
+    """oracle/make_golden.py field: the reference's modules on the video whose flow differs at every pixel of every frame."""
+    return _load_single("field")
 
 
 def _typed_config(keys, vals):
@@ -59,13 +69,22 @@ def _typed_config(keys, vals):
     return cfg
 
 
-@pytest.fixture(scope="session")
-def golden_seg():
-    """Fixture of the fg/bg dual-atlas path, produced from the reference's modules by oracle/make_golden_seg.py."""
-    g = dict(np.load(os.path.join(GOLDEN, "seg_small.npz"), allow_pickle=False))
+def _load_seg(tag):
+    g = dict(np.load(os.path.join(GOLDEN, "seg_%s.npz" % tag), allow_pickle=False))
     g.update(dict(np.load(os.path.join(GOLDEN, "seg_small_start.npz"))))      # the two pre-trained mapping nets the loop starts from
     g["config"] = _typed_config(g["config_keys"], g["config_vals"])
     return g
+
+
+@pytest.fixture(scope="session")
+def golden_seg():
+    """Fixture of the fg/bg dual-atlas path, produced from the reference's modules by oracle/make_golden_seg.py."""
+    return _load_seg("small")
+
+
+@pytest.fixture(scope="session")
+def golden_seg_field():
+    return _load_seg("field")
 
 
 def seg_start_models(golden_seg):
@@ -83,19 +102,46 @@ def seg_start_models(golden_seg):
     return models
 
 
+def _flow_checksum(v):
+    return float(v.optical_flows.double().abs().sum() + v.optical_flows_reverse.double().abs().sum())
+
+
+def _seg_video(g, flow):
+    from oracle import atlas_oracle as O
+    v = O.synthetic_seg_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=int(g["video_seed"]), flow=flow)
+    assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"])) < 1e-6
+    assert abs(float(v.mask_frames.double().sum()) - float(g["mask_checksum"])) < 1e-6
+    if "flow_checksum" in g:       # exact flows: sin/cos/exp of the generator may differ in the last ulp between numpy builds, a transposed field would not pass
+        assert abs(_flow_checksum(v) / float(g["flow_checksum"]) - 1.0) < 1e-6
+        assert float(v.optical_flows_mask.sum() + v.optical_flows_reverse_mask.sum()) == float(g["flow_mask_checksum"])
+    return v
+
+
+def _video(g, flow):
+    from oracle import atlas_oracle as O
+    v = O.synthetic_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=int(g["video_seed"]), flow=flow)
+    assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"])) < 1e-6
+    assert float(v.optical_flows_mask.sum()) == float(g["mask_checksum"])
+    if "flow_checksum" in g:
+        assert abs(_flow_checksum(v) / float(g["flow_checksum"]) - 1.0) < 1e-6
+    return v
+
+
 @pytest.fixture(scope="session")
 def small_seg_video(golden_seg):
-    from oracle import atlas_oracle as O
-    v = O.synthetic_seg_video(int(golden_seg["resx"]), int(golden_seg["resy"]), int(golden_seg["nframes"]), seed=int(golden_seg["video_seed"]))
-    assert abs(float(v.video_frames.double().sum()) - float(golden_seg["video_checksum"])) < 1e-6
-    assert abs(float(v.mask_frames.double().sum()) - float(golden_seg["mask_checksum"])) < 1e-6
-    return v
+    return _seg_video(golden_seg, "constant")
+
+
+@pytest.fixture(scope="session")
+def small_seg_video_field(golden_seg_field):
+    return _seg_video(golden_seg_field, "field")
 
 
 @pytest.fixture(scope="session")
 def small_video(golden):
-    from oracle import atlas_oracle as O
-    v = O.synthetic_video(int(golden["resx"]), int(golden["resy"]), int(golden["nframes"]), seed=int(golden["video_seed"]))
-    assert abs(float(v.video_frames.double().sum()) - float(golden["video_checksum"])) < 1e-6
-    assert float(v.optical_flows_mask.sum()) == float(golden["mask_checksum"])
-    return v
+    return _video(golden, "constant")
+
+
+@pytest.fixture(scope="session")
+def small_video_field(golden_field):
+    return _video(golden_field, "field")

@@ -1,6 +1,10 @@
 """GPU tests at BASELINE.json's full sizes (80 frames x 768x432, samples_batch 10 000) and the domain's
 size-independent properties: one full-size iteration against the CPU oracle on the same sampled indices,
-bit-reproducibility, the reference's convergence anchor and edge cases."""
+bit-reproducibility, the reference's convergence anchor and edge cases.
+
+Since round 4 the full-size videos are `bench.synth_video_device(..., flow="field")`: a different similarity motion every frame, so
+the flow differs at every pixel, nothing is dyadic, and the reference's consistency rule leaves holes in the masks (VERDICT round 3,
+weak #1: on the constant (1.5, 0.5) field a transposed flow gather or a mis-rounded advected coordinate would have passed)."""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +25,7 @@ def full():
     import bench
     dev = torch.device("cuda", 0)
     resx, resy, F = 768, 432, 80
-    video = bench.synth_video_device(resx, resy, F, seed=0, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=0, device=dev, flow="field")
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
     af.upload_video(*video)
     sds = bench.init_state_dicts(1234)
@@ -141,7 +145,7 @@ def test_full_size_seg_iteration_matches_oracle():
     from oracle import atlas_oracle as O
     dev = torch.device("cuda", 0)
     resx, resy, F = 768, 432, 80
-    video = bench.synth_video_device(resx, resy, F, seed=1, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=1, device=dev, flow="field")
     fg = bench.synth_fg_mask_device(resx, resy, F, seed=1, device=dev)
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=True))
     af.upload_video(*video, fg)
@@ -198,7 +202,7 @@ def test_full_size_seg_trajectory_matches_oracle():
     from oracle import atlas_oracle as O
     dev = torch.device("cuda", 0)
     resx, resy, F = 768, 432, 80
-    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev, flow="field")
     fg = bench.synth_fg_mask_device(resx, resy, F, seed=2, device=dev)
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=True))
     af.upload_video(*video, fg)
@@ -268,7 +272,7 @@ def test_long_run_is_bit_reproducible(two_layer):
     import bench
     dev = torch.device("cuda", 0)
     resx, resy, F = 768, 432, 80
-    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev, flow="field")
     if two_layer:
         video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=4, device=dev),)
     sds = bench.init_state_dicts(99, two_layer)
@@ -403,6 +407,11 @@ def _records_from_source(video, inds, resx, resy):
     dx = torch.where((x + 1 < resx)[:, None], frames[y, (x + 1).clamp(max=resx - 1), :, f] - rgb, torch.zeros_like(rgb))
     dy = torch.where((y + 1 < resy)[:, None], frames[(y + 1).clamp(max=resy - 1), x, :, f] - rgb, torch.zeros_like(rgb))
     fg = video[5][y, x, f] if len(video) > 5 else torch.zeros_like(mask[y, x, f])
+    # the comparison means something only on a flow that differs from pixel to pixel (round 4: flow="field"; columns 9..12 = fwd u, v, bwd u, v)
+    mid = (f > 0) & (f < frames.shape[3] - 1)
+    for t in (flows[y, x, 0, f][mid], flows[y, x, 1, f][mid], flows_rev[y, x, 0, f][mid], flows_rev[y, x, 1, f][mid]):
+        assert torch.unique(t).numel() > 0.95 * t.numel()
+    assert 0.02 < 1.0 - float(mask[y, x, f][mid].mean()) < 0.5                 # masks with holes: some sampled pixels are invalid
     return torch.cat((rgb, dx, dy, flows[y, x, :, f], flows_rev[y, x, :, f], mask[y, x, f][:, None], mask_rev[y, x, f][:, None], fg[:, None]), dim=1).cpu().numpy()
 
 
@@ -414,7 +423,7 @@ def test_200_frames_iteration_matches_oracle_and_table_is_exact():
     from oracle import atlas_oracle as O
     dev = torch.device("cuda", 0)
     resx, resy, F = 768, 432, 200
-    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=2, device=dev, flow="field")
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
     af.upload_video(*video)
     P = F * resx * resy
@@ -447,7 +456,7 @@ def test_200_frames_1080p_table_resident_in_hbm():
     import bench
     dev = torch.device("cuda", 0)
     resx, resy, F = 1920, 1080, 200
-    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev)
+    video = bench.synth_video_device(resx, resy, F, seed=4, device=dev, flow="field")
     video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=4, device=dev),)
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
     af.upload_video(*video)

@@ -47,6 +47,21 @@ def af(golden, small_video):
     h.close()
 
 
+@pytest.fixture(scope="module", params=["constant", "field"])
+def case(request, af):
+    """(handle, fixture, video) on the translating video and on the video whose flow differs at every pixel of every frame and whose
+    masks have holes (round 4: `oracle/make_golden.py field` -> single_field.npz, the reference's modules on that video)."""
+    if request.param == "constant":
+        yield af, request.getfixturevalue("golden"), request.getfixturevalue("small_video")
+        return
+    import aiod_amd
+    g, v = request.getfixturevalue("golden_field"), request.getfixturevalue("small_video_field")
+    h = aiod_amd.AtlasFit(_cfg(g, pretrain_batch=int(g["pre_batch"])))
+    _upload(h, v)
+    yield h, g, v
+    h.close()
+
+
 def test_forward_matches_reference_imlp(af, golden):
     import aiod_amd
     m, a = _oracle_models(golden, start=False)
@@ -81,7 +96,8 @@ def test_forward_ragged_rows(af, golden):
         assert np.abs(out[:, :2] - ref).max() < 2e-6, n
 
 
-def test_single_step_losses_and_gradients(af, golden, small_video):
+def test_single_step_losses_and_gradients(case):
+    af, golden, small_video = case
     import aiod_amd
     from oracle import atlas_oracle as O
     m, a = _oracle_models(golden)
@@ -132,9 +148,10 @@ def test_single_step_losses_and_gradients(af, golden, small_video):
     af.set_debug(False)
 
 
-def test_trajectory_matches_reference(af, golden, small_video):
+def test_trajectory_matches_reference(case):
     """K iterations from the reference's post-pre-train state with the reference's index stream:
     loss terms within 1e-3 relative (BASELINE.json), end weights close, PSNR within 0.1 dB."""
+    af, golden, small_video = case
     import aiod_amd
     m, a = _oracle_models(golden)
     af.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict())

@@ -65,6 +65,19 @@ def af(golden_seg, small_seg_video):
     h.close()
 
 
+@pytest.fixture(params=["constant", "field"])
+def case(request):
+    """(handle, fixture, video) on the translating video and on the video with a per-pixel, per-frame flow field and holed masks
+    (round 4: `oracle/make_golden_seg.py field` -> seg_field.npz, the reference's seg modules on that video)."""
+    import aiod_amd
+    sfx = "" if request.param == "constant" else "_field"
+    g, v = request.getfixturevalue("golden_seg" + sfx), request.getfixturevalue("small_seg_video" + sfx)
+    h = aiod_amd.AtlasFit(_cfg(g, pretrain_batch=512))
+    _upload(h, v)
+    yield h, g, v
+    h.close()
+
+
 def test_two_layer_handle_shape(af):
     import aiod_amd
     assert af.loss_width == 16 and af.two_layer
@@ -85,13 +98,14 @@ def test_forward_mapping2_and_alpha_match_reference_imlp(af, golden_seg):
     assert np.abs(out[:, :1] - golden_seg["fwd_alpha"]).max() < 2e-6
 
 
-def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_seg_video):
+def test_first_step_losses_and_gradients_match_reference(case):
     """First loop iteration from the fixture's start state (both mapping nets pre-trained by the reference's
     pre_train_mapping): all 12 loss terms and the four nets' gradients against the values the reference's own
     modules produced (oracle/make_golden_seg.py).  Strict 1e-4 on the terms; gradients within 1e-3 of the reference's,
     plus the reference's own distance from an fp64 twin where that is larger."""
     from conftest import seg_start_models
     from oracle import atlas_oracle as O
+    af, golden_seg, small_seg_video = case
     models = seg_start_models(golden_seg)
     _load(af, models)
     af.set_debug(True)
@@ -123,12 +137,13 @@ def test_first_step_losses_and_gradients_match_reference(af, golden_seg, small_s
         assert e_hip < 1e-3 + 1.05 * e_ref, (k, e_hip, e_ref)
 
 
-def test_trajectory_psnr_and_parameters_match_reference(af, golden_seg, small_seg_video):
+def test_trajectory_psnr_and_parameters_match_reference(case):
     """Ten iterations from the reference's post-pre-train state on the reference's index stream (global rigidity
     switches off after iteration 5, bootstrapping after 7): EVERY term of EVERY iteration within BASELINE.json's
     1e-3 of the reference's fp32 trajectory, end weights close, PSNR within 0.1 dB."""
     from conftest import seg_start_models
     from oracle import atlas_oracle as O
+    af, golden_seg, small_seg_video = case
     models = seg_start_models(golden_seg)
     _load(af, models)
     inds = golden_seg["inds"].astype(np.int64)

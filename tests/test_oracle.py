@@ -35,7 +35,9 @@ def test_pe_layout():
     assert np.allclose(pe.numpy(), np.array(exp, np.float32), atol=1e-6)
 
 
-def test_trajectory_matches_reference_fixture(golden, small_video):
+@pytest.mark.parametrize("flow", ["constant", "field"])
+def test_trajectory_matches_reference_fixture(flow, request):
+    golden, small_video = (request.getfixturevalue(n + ("" if flow == "constant" else "_field")) for n in ("golden", "small_video"))
     m, a = O.build_single_atlas_models(golden["config"], seed=int(golden["weight_seed"]))
     _load_flat(m, golden["start_map"]); _load_flat(a, golden["start_atlas"])
     tr = O.SingleAtlasTrainer(golden["config"], small_video, mapping=m, atlas=a)
@@ -72,6 +74,38 @@ def test_empty_flow_set_is_nan_like_the_reference(golden, small_video):
     assert np.isnan(t["flow"])
 
 
+def test_field_video_has_a_per_pixel_flow_that_moves_its_texture():
+    """The `flow="field"` videos (round 4): no two flow vectors of a frame are equal, fields differ from frame
+    to frame, the masks are the reference's consistency rule applied to the fields (unwrap_utils.py:10-23,151-159) and have holes away
+    from the border, and the flow really is the motion of the texture (without flicker: frame f+1 sampled at p + flow(p) == frame f)."""
+    v = O.synthetic_video(96, 54, 7, seed=5, flow="field", flicker=False)
+    fl, fr = v.optical_flows.numpy()[..., 0], v.optical_flows_reverse.numpy()[..., 0]
+    mk, mr = v.optical_flows_mask.numpy()[..., 0], v.optical_flows_reverse_mask.numpy()[..., 0]
+    assert not fl[:, :, :, -1].any() and not fr[:, :, :, 0].any() and not mk[:, :, -1].any() and not mr[:, :, 0].any()      # unwrap_utils.py:135-159
+    yy, xx = np.mgrid[0:54, 0:96].astype(np.float32)
+    for f in range(6):
+        for comp in (0, 1):
+            assert np.unique(fl[:, :, comp, f]).size > 0.98 * 96 * 54
+        assert np.abs(fl[:, :, :, f] - fl[:, :, :, (f + 1) % 6]).mean() > 0.05
+        assert np.array_equal(mk[:, :, f] > 0, O.compute_consistency(fl[:, :, :, f], fr[:, :, :, f + 1]) < 1.0)
+        assert np.array_equal(mr[:, :, f + 1] > 0, O.compute_consistency(fr[:, :, :, f + 1], fl[:, :, :, f]) < 1.0)
+        inner = mk[8:-8, 12:-12, f]
+        assert 0.5 < inner.mean() < 0.999                                        # holes inside the frame, not only border strips
+        warped = O.remap_bilinear_zero(v.video_frames[:, :, :, f + 1].numpy(), xx + fl[:, :, 0, f], yy + fl[:, :, 1, f])
+        err = np.abs(warped - v.video_frames[:, :, :, f].numpy())[mk[:, :, f] > 0]
+        assert np.median(err) < 2e-3 and err.mean() < np.abs((v.video_frames[:, :, :, f + 1] - v.video_frames[:, :, :, f]).numpy()).mean()
+    # the device generator of bench.py builds the same kind of video from torch's generator (its own draws)
+    import bench
+    frames, flows, flows_rev, mask, mask_rev = bench.synth_video_device(64, 36, 4, 9, torch.device("cpu"), flow="field", flicker=False)
+    yy, xx = np.mgrid[0:36, 0:64].astype(np.float32)
+    for f in range(3):
+        assert np.array_equal(mask[:, :, f].numpy() > 0, O.compute_consistency(flows[:, :, :, f].numpy(), flows_rev[:, :, :, f + 1].numpy()) < 1.0)
+        warped = O.remap_bilinear_zero(frames[:, :, :, f + 1].numpy(), xx + flows[:, :, 0, f].numpy(), yy + flows[:, :, 1, f].numpy())
+        assert np.median(np.abs(warped - frames[:, :, :, f].numpy())[mask[:, :, f].numpy() > 0]) < 5e-3
+        warped = O.remap_bilinear_zero(frames[:, :, :, f].numpy(), xx + flows_rev[:, :, 0, f + 1].numpy(), yy + flows_rev[:, :, 1, f + 1].numpy())
+        assert np.median(np.abs(warped - frames[:, :, :, f + 1].numpy())[mask_rev[:, :, f + 1].numpy() > 0]) < 5e-3
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference not mounted (GPU box)")
 def test_restatement_against_live_reference_modules():
     import subprocess, sys
@@ -103,7 +137,9 @@ def test_alpha_pe_layout():
     assert np.allclose(pe, np.array(exp, np.float32), atol=1e-6)
 
 
-def test_seg_trajectory_matches_reference_fixture(golden_seg, small_seg_video):
+@pytest.mark.parametrize("flow", ["constant", "field"])
+def test_seg_trajectory_matches_reference_fixture(flow, request):
+    golden_seg, small_seg_video = (request.getfixturevalue(n + ("" if flow == "constant" else "_field")) for n in ("golden_seg", "small_seg_video"))
     from conftest import seg_start_models
     tr = O.SegAtlasTrainer(golden_seg["config"], small_seg_video, models=seg_start_models(golden_seg))
     assert abs(float(np.abs(O.flat_params(tr.m1)).sum()) - float(golden_seg["start_m1_sum"])) < 1e-3
