@@ -72,8 +72,8 @@ def shipped_config():
     return dict(mod.REFERENCE_CONFIG)
 
 
-def run_seed(seed, c, double=False):
-    video = O.synthetic_video(RESX, RESY, NF, seed=seed)
+def run_seed(seed, c, double=False, flow="constant"):
+    video = O.synthetic_video(RESX, RESY, NF, seed=seed, flow=flow)
     torch.manual_seed(seed)
     # stage1_neural_atlas.py:112-128 (mapping first, then atlas)
     rm = IMLP(input_dim=3, output_dim=2, hidden_dim=256, use_positional=False, positional_dim=4, num_layers=6, skip_layers=[], verbose=False)
@@ -115,14 +115,20 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c1_reference.npz"))
     ap.add_argument("--double", action="store_true", help="run the schedule in fp64 from the fp32 initial weights (diagnostic: where exact arithmetic lands)")
-    ap.add_argument("--merge", nargs="+", default=None, help="stack per-seed files written by earlier invocations (same thread count) into --out")
+    ap.add_argument("--merge", nargs="+", default=None, help="stack per-seed files written by earlier invocations into --out (thread counts and flow kinds are kept per seed)")
+    ap.add_argument("--flow", default="constant", choices=["constant", "field"], help="round 4: 'field' = oracle.atlas_oracle.synthetic_video(flow='field'), a per-pixel, per-frame flow field with holed masks")
     args = ap.parse_args()
     if args.merge:
         parts = [dict(np.load(f)) for f in args.merge]
         parts.sort(key=lambda d: int(d["seeds"][0]))
-        assert len({int(d["threads"]) for d in parts}) == 1 and len({int(d["iters"]) for d in parts}) == 1
-        out = {k: parts[0][k] for k in ("resx", "resy", "nframes", "iters", "pretrain_iters", "log_every", "threads")}
-        for k in ("seeds", "psnr_pre", "psnr", "psnr_per_frame", "curves", "cpu_seconds", "video_checksum"):
+        assert len({int(d["iters"]) for d in parts}) == 1
+        for d in parts:         # files written before round 4 carry one thread count and no flow kind
+            n = len(d["seeds"])
+            d["threads_per_seed"] = d.get("threads_per_seed", np.full(n, int(d["threads"])))
+            d["flow_kind"] = d.get("flow_kind", np.array(["constant"] * n))
+        out = {k: parts[0][k] for k in ("resx", "resy", "nframes", "iters", "pretrain_iters", "log_every")}
+        out["threads"] = parts[0]["threads"] if len({int(d["threads"]) for d in parts}) == 1 else np.int64(-1)
+        for k in ("seeds", "psnr_pre", "psnr", "psnr_per_frame", "curves", "cpu_seconds", "video_checksum", "threads_per_seed", "flow_kind"):
             out[k] = np.concatenate([d[k] for d in parts], axis=0)
         np.savez_compressed(args.out, **out)
         print("merged", [int(x) for x in out["seeds"]], "->", args.out, "PSNR", np.array2string(out["psnr"], precision=3))
@@ -130,13 +136,14 @@ def main():
     if args.threads > 0:
         torch.set_num_threads(args.threads)
     c = shipped_config()
-    res = [run_seed(s, c, args.double) for s in args.seeds]
+    res = [run_seed(s, c, args.double, args.flow) for s in args.seeds]
     np.savez_compressed(
         args.out, seeds=np.array(args.seeds), resx=RESX, resy=RESY, nframes=NF, iters=ITERS, pretrain_iters=PRETRAIN_ITERS, log_every=LOG_EVERY,
         psnr_pre=np.array([r["psnr_pre"] for r in res]), psnr=np.array([r["psnr"] for r in res]),
         psnr_per_frame=np.stack([r["per_frame"] for r in res]), curves=np.stack([r["curve"] for r in res]),
         cpu_seconds=np.array([[r["t_pre"], r["t_loop"]] for r in res]), threads=torch.get_num_threads(),
         video_checksum=np.array([r["video_checksum"] for r in res]),
+        threads_per_seed=np.full(len(res), torch.get_num_threads()), flow_kind=np.array([args.flow] * len(res)),
     )
     print("written", args.out, "PSNR", [r["psnr"] for r in res])
 

@@ -46,7 +46,7 @@ PRETRAIN_ITERS = 100                   # config_flow_100.json "pretrain_iter_num
 LOG_EVERY = 100
 
 
-def run(seed, threads, double=False):
+def run(seed, threads, double, flow="constant"):
     from oracle.make_golden_c1 import shipped_config                                # also puts /root/reference on sys.path
     from oracle.make_golden_seg import ref_models, ref_seg_iteration
     from oracle import atlas_oracle as O
@@ -54,7 +54,7 @@ def run(seed, threads, double=False):
     if threads > 0:
         torch.set_num_threads(threads)
     c = shipped_config()
-    video = O.synthetic_seg_video(RESX, RESY, NF, seed=seed)
+    video = O.synthetic_seg_video(RESX, RESY, NF, seed=seed, flow=flow)
     m1, m2, at, al = ref_models(seed)           # torch.manual_seed(seed); mapping1, mapping2, atlas, alpha
     if double:
         for m in (m1, m2, at, al):
@@ -90,7 +90,7 @@ def run(seed, threads, double=False):
           % (seed, psnr_pre, psnr, ITERS, t_pre, t_loop), flush=True)
     return dict(seed=seed, threads=torch.get_num_threads(), double=int(double), psnr_pre=psnr_pre, psnr=psnr, per_frame=np.array(per),
                 curve=np.array(curve, np.float64), cpu_seconds=np.array([t_pre, t_loop]),
-                video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.mask_frames.double().sum()))
+                video_checksum=float(video.video_frames.double().sum()), mask_checksum=float(video.mask_frames.double().sum()), flow_kind=flow)
 
 
 def merge(paths, out):
@@ -103,7 +103,8 @@ def merge(paths, out):
         psnr_pre=np.array([float(r["psnr_pre"]) for r in runs]), psnr=np.array([float(r["psnr"]) for r in runs]),
         psnr_per_frame=np.stack([r["per_frame"] for r in runs]), curves=np.stack([r["curve"] for r in runs]),
         cpu_seconds=np.stack([r["cpu_seconds"] for r in runs]),
-        video_checksum=np.array([float(r["video_checksum"]) for r in runs]), mask_checksum=np.array([float(r["mask_checksum"]) for r in runs]))
+        video_checksum=np.array([float(r["video_checksum"]) for r in runs]), mask_checksum=np.array([float(r["mask_checksum"]) for r in runs]),
+        flow_kind=np.array([str(r.get("flow_kind", "constant")) for r in runs]))
     print("merged %d runs into %s" % (len(runs), out))
     for r in runs:
         print("  seed %d threads %d %s: PSNR %.4f dB" % (int(r["seed"]), int(r["threads"]), "fp64" if int(r["double"]) else "fp32", float(r["psnr"])))
@@ -115,11 +116,12 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--double", action="store_true", help="the same modules, initial weights and draws in fp64 (diagnostic arm)")
     ap.add_argument("--merge", nargs="+", default=None)
+    ap.add_argument("--flow", default="constant", choices=["constant", "field"], help="round 4: 'field' = a per-pixel, per-frame flow field with holed masks")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     if args.merge:
         return merge(args.merge, args.out)
-    r = run(args.seed, args.threads, args.double)
+    r = run(args.seed, args.threads, args.double, args.flow)
     np.savez_compressed(args.out, **r)
     print("written", args.out)
 

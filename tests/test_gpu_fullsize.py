@@ -196,7 +196,13 @@ def test_full_size_seg_trajectory_matches_oracle():
     """BASELINE configs[4] at its real size over CONSECUTIVE Adam steps (the full-size fg/bg evidence was single-step):
     both mapping nets pre-trained on the device, the state copied into the CPU oracle, then TEN iterations of the four-net packed
     launch plan on the same injected indices straddling the global-rigidity switch (i = 4996..5005, stage1_neural_atlas_seg.py:
-    193-315, stop_global_rigidity 5000): all 12 loss terms of every iteration within BASELINE.json's 1e-3, end weights close."""
+    193-315, stop_global_rigidity 5000): all 12 loss terms of every iteration within BASELINE.json's 1e-3, end weights close.
+
+    Round 4 (field-flow video): two fp32 trajectories of this loop separate by themselves — Adam moves a weight whose gradient is ~0 by
+    +-lr on the sign of round-off, and the atlas net's 2^9 pi Fourier features turn that into 1e-3 of the gradient-loss term within
+    six steps.  An fp64 twin of the oracle runs beside the fp32 one from the same state: the 1e-3 is widened by the torch-fp32
+    trajectory's OWN measured distance from the fp64 one on that term and iteration, and by nothing else; the HIP trajectory must
+    also be no further from fp64 than that."""
     import aiod_amd
     import bench
     from oracle import atlas_oracle as O
@@ -220,24 +226,39 @@ def test_full_size_seg_trajectory_matches_oracle():
     v = O.SegVideo(frames, flows[..., None], flows_rev[..., None], mask[..., None], mask_rev[..., None], fg.cpu())
     models = O.build_seg_models(cfg, seed=0)
     _copy_params_to_oracle(af, nets, models)
+    import copy
+    m64 = [copy.deepcopy(m).double() for m in models]
+    for m in m64:
+        if m.use_positional:
+            m.b = m.b.double()
+    v64 = O.SegVideo(frames.double(), flows[..., None].double(), flows_rev[..., None].double(), mask[..., None], mask_rev[..., None], fg.cpu().double())
     tr = O.SegAtlasTrainer(cfg, v, models=models)
+    tr64 = O.SegAtlasTrainer(cfg, v64, models=m64)
     g = torch.Generator().manual_seed(29)
     K, first, N = 10, 4996, cfg["samples_batch"]
     inds = torch.randint(F * resx * resy, (K, N), generator=g)
     hip = af.train_steps(first, K, inds.numpy())
-    worst = 0.0
+    worst = worst_excess = 0.0
     for k in range(K):
         t = tr.step(first + k, inds[k])
-        want = np.array([t[n] for n in O.SEG_TERMS])
+        torch.set_default_dtype(torch.float64)          # coordinate normalisation follows the default dtype
+        try:
+            t64 = tr64.step(first + k, inds[k])
+        finally:
+            torch.set_default_dtype(torch.float32)
+        want, f64 = np.array([t[n] for n in O.SEG_TERMS]), np.array([t64[n] for n in O.SEG_TERMS])
         on = np.abs(want) > 0
-        rel = np.zeros(12)
+        rel, e_ref, e_hip = np.zeros(12), np.zeros(12), np.zeros(12)
         rel[on] = np.abs(hip[k, :12][on] - want[on]) / np.abs(want[on])
+        e_ref[on] = np.abs(want[on] - f64[on]) / np.abs(f64[on])
+        e_hip[on] = np.abs(hip[k, :12][on] - f64[on]) / np.abs(f64[on])
         assert np.all(hip[k, :12][~on] == 0), (first + k, hip[k, :12], want)       # the switched-off global terms are exactly zero on both sides
-        print(first + k, "rel max %.3g" % rel.max(), "global terms", want[4], want[5])
-        assert rel.max() < 1e-3, (first + k, hip[k, :12], want, rel)
+        print(first + k, "max rel: hip-vs-torch-fp32 %.3g (term %d) | vs the fp64 twin: hip %.3g  torch-fp32 %.3g" % (rel.max(), int(rel.argmax()), e_hip.max(), e_ref.max()), "global terms", want[4], want[5])
+        assert np.all(rel <= 1e-3 + 1.05 * e_ref), (first + k, hip[k, :12], want, rel, e_ref)
+        assert np.all(e_hip <= 1e-3 + 1.05 * e_ref), (first + k, hip[k, :12], f64, e_hip, e_ref)
         assert (want[4] > 0) == (first + k <= 5000) and (want[5] > 0) == (first + k <= 5000)
-        worst = max(worst, float(rel.max()))
-    print("full-size two-layer trajectory: worst relative loss-term distance %.3g over %d iterations" % (worst, K))
+        worst = max(worst, float(rel.max())); worst_excess = max(worst_excess, float((rel - 1.05 * e_ref).max()))
+    print("full-size two-layer trajectory: worst relative loss-term distance %.3g over %d iterations (%.3g beyond torch-fp32's own distance from fp64)" % (worst, K, worst_excess))
     for net, mdl in zip(nets, models):
         d = np.abs(af.get_params_flat(net) - O.flat_params(mdl))
         print("end-weight diff net", net, "max %.3g mean %.3g" % (d.max(), d.mean()))

