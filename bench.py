@@ -234,8 +234,14 @@ def cpu_baseline(resx, resy, nframes, seed, sds, video_dev, budget_s, two_layer=
         it = 4000 if n % 2 == 0 else 6000                   # alternate: with / without global rigidity
         tr.step(it, torch.randint(P, (N,), generator=g)); n += 1
     dt = time.perf_counter() - t0
-    return {"value": N * n / dt, "unit": "sampled points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d loop iterations (N=10000, alternating with/without the global-rigidity term) of the oracle restatement, %.1f s" % (n, dt)}
+    out = {"value": N * n / dt, "unit": "sampled points/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d loop iterations (N=10000, alternating with/without the global-rigidity term) of the oracle restatement, %.1f s" % (n, dt)}
+    try:      # the reference's OWN modules cannot run here (/root/reference does not travel): their figure from the build container, for the label only
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_reference.json")))["cpu_baseline"]
+        out["reference_modules_build_container"] = {"value": ref["value"], "cores": ref["cores"], "source": "profiles/r2_cpu_reference.json (not this host)"}
+    except Exception:
+        pass
+    return out
 
 
 def timed_region(run, sync, dist=None, device=None):
@@ -253,11 +259,43 @@ def timed_region(run, sync, dist=None, device=None):
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    timed_region.local_seconds = dt                      # this rank's own window (rank_stats gathers them)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def rank_stats(local_seconds, steps, device_name, dist=None, device=None):
+    """Per-rank view of the timed window for the JSON line: every rank's ms/step and device name (gathered with the process group's
+    own collectives, outside the timed region)."""
+    import torch
+    if dist is None:
+        return {"ms_per_step_min": local_seconds / steps * 1e3, "ms_per_step_max": local_seconds / steps * 1e3, "ms_per_step_by_rank": [local_seconds / steps * 1e3],
+                "devices": [device_name]}
+    world = dist.get_world_size()
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
+    ts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    names = [None] * world
+    try:
+        dist.all_gather_object(names, device_name)
+    except Exception as e:                               # the names are informational; the timing is not
+        names = [device_name] + ["(all_gather_object failed: %r)" % (e,)] * (world - 1)
+    ms = [float(x.item()) / steps * 1e3 for x in ts]
+    return {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step_by_rank": ms, "devices": names}
+
+
+def check_gpu_count(n_gpus):
+    """SURVEY.md 7, last bullet: enumerate the visible devices and say what is there BEFORE any rank dies in set_device."""
+    import torch
+    seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_gpus > seen:
+        names = [torch.cuda.get_device_name(i) for i in range(seen)]
+        sys.exit("bench.py: --gpus %d but this process sees %d GPU(s) %s (HIP_VISIBLE_DEVICES=%s, ROCR_VISIBLE_DEVICES=%s): one rank per GPU, nothing launched"
+                 % (n_gpus, seen, names, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+    return seen
 
 
 def shard_for_rank(rank, world, n_videos=None):
@@ -274,6 +312,8 @@ def self_spawn(n_gpus, argv):
         so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # N ranks build their synthetic videos and states at once: cap the host threads of each so they do not oversubscribe the node
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
     sys.stdout.flush(); sys.stderr.flush()
     os.execv(sys.executable, cmd)
 
@@ -289,10 +329,12 @@ def dry_run(backend, args):
         dist.init_process_group(backend)
     assert args.gpus == world, (args.gpus, world)
     dt = timed_region(lambda: time.sleep(0.01 * (rank + 1)), lambda: None, dist if world > 1 else None, torch.device("cpu"))
+    st = rank_stats(timed_region.local_seconds, 1, "cpu:%d" % rank, dist if world > 1 else None, torch.device("cpu"))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "backend": backend, "n_gpus": world, "video_of_rank0": shard_for_rank(0, world), "max_region_s": dt}))
+        print(json.dumps({"dry_run": True, "backend": backend, "n_gpus": world, "video_of_rank0": shard_for_rank(0, world), "max_region_s": dt,
+                          "ranks": st, "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "videos": [shard_for_rank(r, world) for r in range(world)]}))
 
 
 def model_rows(it, N, p_valid, two_layer, stop_global=5000):
@@ -363,6 +405,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:         # bare `python bench.py --gpus N`: spawn the N ranks ourselves
+        if not os.environ.get("AF_BENCH_DRY_RUN"):
+            check_gpu_count(args.gpus)
         return self_spawn(args.gpus, sys.argv[1:])
     if os.environ.get("AF_BENCH_DRY_RUN"):
         return dry_run(os.environ["AF_BENCH_DRY_RUN"], args)
@@ -371,6 +415,9 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    n_visible = check_gpu_count(max(args.gpus, local + 1))      # a launcher that started more ranks than there are GPUs: say so, once per rank, before set_device
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -453,6 +500,7 @@ def main():
         for t in ths:
             t.join()
     dt = timed_region(run_all, torch.cuda.synchronize, dist if world > 1 else None, dev)
+    ranks = rank_stats(timed_region.local_seconds, K, torch.cuda.get_device_name(local), dist if world > 1 else None, dev)
     tk = af.timing(reset=True)
 
     # ---- per-kernel pass (NOT the timed region): the same K iterations once more, HIP events around every launch, clocks as
@@ -543,7 +591,7 @@ def main():
         value = world * V * N * K / dt
         out = {
             "metric": METRIC, "value": value, "unit": "sampled points/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "n_gpus": world, "n_gpus_visible": n_visible, "ranks": ranks, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (" + "; ".join(x for x in (
                 ("MLP chains bf16x6: operands split into 3 bf16, 6 partial products" + (" (EXPERIMENT: backward chain on 3 products)" if MLP_MODE == 2 else "")) if MLP_BF else "",
