@@ -164,7 +164,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
 // ------------------------------------------------------------------------------------------------
 // The same contraction on the bf16 matrix pipe with fp32-faithful operands ("bf16x6"): every fp32 operand element is
 // split in registers into three bf16 values hi + mid + lo (8 + 8 + 8 mantissa bits; the two residuals are exact fp32
-// subtractions, so hi + mid + lo == x to within 2^-25 |x|), and a product a*b is accumulated as the six partial
+// subtractions, so hi + mid + lo == x to within 2^-24 |x|), and a product a*b is accumulated as the six partial
 // products hh + hm + mh + mm + hl + lh in the MFMA's fp32 accumulator.  The dropped terms (ml, lm, ll) are <= 2^-23
 // |ab| — the size of the rounding of ONE fp32 multiply — so the result carries fp32-level round-off (measured against
 // fp64 on a 90 000-row contraction: 1.5e-7 relative, vs 2.3e-7 for a plain fp32 GEMM; tests/test_split_precision.py

@@ -588,8 +588,9 @@ int enqueue_single_step(af_handle* h, int i, const int64_t* d_inds, uint64_t see
     p.d_local = c.derivative_amount; p.d_global = c.global_rigidity_derivative_amount_fg; p.nseg = nseg;
     p.coords = M.coords; p.x0_tile = M.x0_tile; p.samples = h->samples; p.counts = h->counts;
     p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
-    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets; h->prep_tickets += (unsigned long long)((N + 255) / 256);
+    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets;
     LCHK(af_launch_prep(&p, h->stream));
+    h->prep_tickets += (unsigned long long)((N + 255) / 256);      // only a launch that went out takes tickets: the device counter and this base must not part
   }
   // Launch 1: the whole rounds of the mapping batch (they hold the 3N rows the atlas reads).  Launch 2: the atlas
   // chain plus the mapping remainder — rigidity / flow rows nothing in this launch depends on — in the CUs the
@@ -648,8 +649,9 @@ int enqueue_seg_step(af_handle* h, int i, const int64_t* d_inds, uint64_t seed, 
     p.coords = M1.coords; p.x0_tile = M1.x0_tile; p.samples = h->samples; p.counts = h->counts;
     p.coords2 = M2.coords; p.x0_tile2 = M2.x0_tile; p.coordsA = AL.coords; p.d_global2 = c.global_rigidity_derivative_amount_bg;
     p.flow_rank = h->flow_rank; p.scan = h->scan; p.live = h->live; p.epoch = ++h->prep_epoch;
-    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets; h->prep_tickets += (unsigned long long)((N + 255) / 256);
+    p.ticket = h->scan + (N + 255) / 256; p.ticket_base = h->prep_tickets;
     LCHK(af_launch_prep(&p, h->stream));
+    h->prep_tickets += (unsigned long long)((N + 255) / 256);      // only a launch that went out takes tickets: the device counter and this base must not part
   }
   // Launch 1: alpha, mapping1, mapping2 (longest chains first, so the launch drains on the short ones).
   // Launch 2: the atlas chain — rows [0,3N) = uv1*0.5+0.5 (foreground quadrant), [3N,6N) = uv2*0.5-0.5
@@ -822,6 +824,11 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   CCHK(dalloc(&h->img_f, fc)); CCHK(dalloc(&h->img_b, bc)); CCHK(dalloc(&h->bias_img, biasc));
   CCHK(hipMemset(h->params, 0, pc * 4)); CCHK(hipMemset(h->adam_m, 0, pc * 4)); CCHK(hipMemset(h->adam_v, 0, pc * 4));
   CCHK(hipMemset(h->pre_m, 0, pc * 4)); CCHK(hipMemset(h->pre_v, 0, pc * 4)); CCHK(hipMemset(h->grads, 0, pc * 4));
+  // INVARIANT: image slots no parameter maps to stay EXACTLY zero for the life of the handle.  The PE stages always walk
+  // their shipped slot layout (`peg` above: five 3-D / ten 2-D frequencies) and padded K rows; k_adam, load_state_dict and the
+  // repack of a mode switch only ever write the slots af_img_index() gives a real parameter, so the zeros written here are what
+  // carries positional_encoding_num_* below the shipped count and the K padding.  Guard: tests/test_gpu_arch.py trains such
+  // configurations for several Adam steps against the oracle (a slot that picked up a value would show in the second step's losses).
   CCHK(hipMemset(h->img_f, 0, fc * 4)); CCHK(hipMemset(h->img_b, 0, bc * 4)); CCHK(hipMemset(h->bias_img, 0, biasc * 4));
   // batch buffers
   h->N = cfg->samples_batch;

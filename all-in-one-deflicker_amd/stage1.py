@@ -457,5 +457,6 @@ if __name__ == "__main__":
         sys.path.insert(0, os.path.dirname(_HERE))
         import aiod_amd  # noqa: F401
         from aiod_amd import stage1 as _s
-        sys.exit(0 if _s._cli() is not None or True else 1)
+        _s._cli()
+        sys.exit(0)
     _cli()

@@ -142,7 +142,7 @@ int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg);
 int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
 /* Arithmetic of the weight-gradient GEMMs (k_dw), for the loop AND for pre_train_mapping's dW: 1 (default) = fp32-faithful
  * "bf16x6" — each fp32 operand split in registers into three bf16 values, the six leading partial products accumulated in
- * fp32 on the bf16 matrix pipe (dropped terms <= 2^-24 relative: tests/test_split_precision.py).  2 (opt-in) = "bf16x3" —
+ * fp32 on the bf16 matrix pipe (dropped terms <= 2^-23 relative: tests/test_split_precision.py).  2 (opt-in) = "bf16x3" —
  * two bf16 values per operand (16 mantissa bits), three partial products: NARROWER than the reference's fp32, faster,
  * measured within 3x of torch-fp32's own gradient error against an fp64 twin at full size (tests/test_gpu_fullsize.py);
  * never the default and never bench.py's headline value.  0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  The three

@@ -2,7 +2,7 @@
 operand is split into three bf16 values (round-to-nearest-even at each level, residuals by exact fp32 subtraction) and a
 product is accumulated as hh + hm + mh + mm + hl + lh in fp32 ("bf16x6": the chains, k_dw_bf<6>).  Checked here: the split
 is (nearly) exact, and the contraction dW = dZ^T X carries fp32-level round-off against an fp64 reference — no more than a
-plain fp32 GEMM.  The three-product form (hi + mid only: k_dw_bf<3>, the weight-gradient GEMM's default) is visibly
+plain fp32 GEMM.  The three-product form (hi + mid only: k_dw_bf<3>, an opt-in of the weight-gradient GEMM since round 3, never the default) is visibly
 coarser per contraction and still far inside what separates an fp32 gradient from its fp64 twin on real batches
 (tests/test_gpu_fullsize.py holds it to that)."""
 import numpy as np
