@@ -137,7 +137,7 @@ def load_library(path=None):
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (must come first: share torch's HIP runtime)
-    path = path or _LIB_PATH
+    path = path or os.environ.get("AF_LIB_PATH") or _LIB_PATH      # AF_LIB_PATH: an experiment build of the same library (tools/ab_step.sh), never a fallback
     if not os.path.exists(path):
         raise AtlasFitError(-100, "libatlasfit.so not built: run `python %s`" % os.path.join(_HERE, "build.py"))
     lib = C.CDLL(path)

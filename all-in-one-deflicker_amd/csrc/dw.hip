@@ -184,6 +184,277 @@ AF_DEV void dw_sgb_spread(std::integer_sequence<int, I...>) {
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)), ...);
 }
 
+// ---- the 8x8 six-product stage as 96 hand-placed issue slots (round 4) -----------------------------------------------------------
+// One wave per SIMD issues in order; an MFMA holds the matrix pipe for 32 cycles and hides at most five light instructions behind
+// it (MI355X_MICROARCH.md: a hand-placed stream with exactly five fillers per gap runs 32.4 cycles per MFMA, the floor; six cost a
+// whole extra issue slot).  The compiler-scheduled stage (dw_sgb_spread below, kept for the other shapes) came out at 4.4 VALU per
+// MFMA on average but unevenly — 100 of 192 gaps with five VALU plus SALU / LDS / DMA on top, clumps of 11-26 behind the barrier,
+// eight DMA pieces in three gaps, ~30 VALU of per-lane 64-bit address arithmetic per stage — and ran 40.8 cycles per MFMA.  Here
+// every slot is written out: slot = one MFMA + its fillers from dw_slots.h (tools/dw_slots_gen.py), fenced by sched_barrier(0):
+//   * the split is a stream of single-instruction micro-ops (dw_split_op), two streams per column (B column y+1, A fragment y of the
+//     next stage + its bias-gradient row sum), interleaved A/B inside a slot so that no instruction waits on its predecessor;
+//   * raw-fragment LDS reads one per slot; LDS-DMA pieces one per slot, almost alone, in the `voff, s[base]` form (inline asm: the
+//     builtin takes a per-lane 64-bit address) — two per column instead of eight behind the barrier;
+//   * the split B operand ping-pongs between two register sets (no copies at the column end).
+// The MFMA order per accumulator is the compiler-scheduled kernel's: results are bit-identical to it (tools/dwbench.hip checks).
+#ifndef DW_SLOT
+#define DW_SLOT 1
+#endif
+#include "dw_slots.h"
+struct DwStream { float t[2][2]; float u; };           // residuals of the two pairs a split stream has in flight (by pair parity) + one widened half
+#define DW_PIN(x) asm volatile("" : "+v"(x))
+// Micro-op K (0..43) of dw_split8<3>(lo4, hi4): one VALU instruction, tied to where it is written.  Per pair of values (a, b) the
+// split is  A h = cvt_pk(a, b) | B r0 = h << 16 | C r1 = h & 0xffff0000 | D r0 = a - r0 | E r1 = b - r1 | F m = cvt_pk(r0, r1) |
+// G u = m << 16 | H r0 -= u | I u = m & 0xffff0000 | J r1 -= u | K l = cvt_pk(r0, r1).  v_cvt_pk_bf16_f32 needs a wait state on
+// either side (hipcc pads a cvt next to its producer / consumer with s_nop - an issue slot gone), so a stream runs the second half of
+// pair i in lock-step with the first half of pair i + 1:  A0 B0 C0 D0 E0 | F0 A1 G0 B1 H0 C1 I0 D1 J0 E1 K0 | F1 A2 ... K2 | F3 G3 H3 I3 J3 K3.
+struct DwOp { int pair, ph; };
+constexpr DwOp dw_op_of(int K) {
+  if (K < 5) return DwOp{0, K};
+  if (K >= 38) return DwOp{3, 5 + (K - 38)};
+  const int i = (K - 5) / 11, j = (K - 5) % 11;
+  return (j & 1) ? DwOp{i + 1, j / 2} : DwOp{i, 5 + j / 2};
+}
+template <int K> AF_DEV void dw_split_op(const f32x4& lo4, const f32x4& hi4, DwSplit& o, DwStream& st) {
+  constexpr DwOp op = dw_op_of(K);
+  constexpr int i = op.pair, ph = op.ph, e = i & 1;
+  const float a = i < 2 ? lo4[2 * i] : hi4[2 * i - 4], b = i < 2 ? lo4[2 * i + 1] : hi4[2 * i - 3];
+  float (&t)[2] = st.t[e];
+  if constexpr (ph == 0)       { uint32_t h = dw_pk(a, b); DW_PIN(h); o.h[i] = h; }
+  else if constexpr (ph == 1)  { float v = __builtin_bit_cast(float, o.h[i] << 16); DW_PIN(v); t[0] = v; }
+  else if constexpr (ph == 2)  { float v = __builtin_bit_cast(float, o.h[i] & 0xffff0000u); DW_PIN(v); t[1] = v; }
+  else if constexpr (ph == 3)  { float v = a - t[0]; DW_PIN(v); t[0] = v; }
+  else if constexpr (ph == 4)  { float v = b - t[1]; DW_PIN(v); t[1] = v; }
+  else if constexpr (ph == 5)  { uint32_t m = dw_pk(t[0], t[1]); DW_PIN(m); o.m[i] = m; }
+  else if constexpr (ph == 6)  { float v = __builtin_bit_cast(float, o.m[i] << 16); DW_PIN(v); st.u = v; }
+  else if constexpr (ph == 7)  { float v = t[0] - st.u; DW_PIN(v); t[0] = v; }
+  else if constexpr (ph == 8)  { float v = __builtin_bit_cast(float, o.m[i] & 0xffff0000u); DW_PIN(v); st.u = v; }
+  else if constexpr (ph == 9)  { float v = t[1] - st.u; DW_PIN(v); t[1] = v; }
+  else                         { uint32_t l = dw_pk(t[0], t[1]); DW_PIN(l); o.l[i] = l; }
+}
+// The A stream = the 44 split micro-ops with the nine micro-ops of the bias-gradient row sum placed between the pair blocks (left at the
+// end they are one serial chain in slots no other stream fills: a dependent VALU instruction right behind its producer costs a wait state):
+// db += ((t0 + t1) + (t2 + t3)) with t = lo4 + hi4 (the 8 rows of the raw fragment) — dw_segment_bf's association.
+// position -> (kind 0: split op K, 1: row-sum op K)
+struct DwAOp { int kind, k; };
+constexpr DwAOp dw_aop_of(int P) {
+  //  0..4 A0..E0 | 5,6 s0 s1 | 7..17 block 0 | 18,19 s2 s3 | 20..30 block 1 | 31,32 s4 s5 | 33..43 block 2 | 44 s6 | 45 F3 | 46 s7 | 47..50 G3..J3 | 51 s8 | 52 K3
+  if (P < 5) return DwAOp{0, P};
+  if (P < 7) return DwAOp{1, P - 5};
+  if (P < 18) return DwAOp{0, P - 2};
+  if (P < 20) return DwAOp{1, P - 16};
+  if (P < 31) return DwAOp{0, P - 4};
+  if (P < 33) return DwAOp{1, P - 27};
+  if (P < 44) return DwAOp{0, P - 6};
+  if (P == 44) return DwAOp{1, 6};
+  if (P == 45) return DwAOp{0, 38};
+  if (P == 46) return DwAOp{1, 7};
+  if (P < 51) return DwAOp{0, P - 8};
+  if (P == 51) return DwAOp{1, 8};
+  return DwAOp{0, 43};
+}
+struct DwSum { float e0, e1, e2; };
+template <int K> AF_DEV void dw_db_op(const f32x4& lo4, const f32x4& hi4, float& db, DwSum& e, bool real) {
+  if constexpr (K == 0)      { float v = lo4[0] + hi4[0]; DW_PIN(v); e.e0 = v; }                  // t0
+  else if constexpr (K == 1) { float v = lo4[1] + hi4[1]; DW_PIN(v); e.e1 = v; }                  // t1
+  else if constexpr (K == 2) { float v = e.e0 + e.e1; DW_PIN(v); e.e0 = v; }                      // t0 + t1
+  else if constexpr (K == 3) { float v = lo4[2] + hi4[2]; DW_PIN(v); e.e1 = v; }                  // t2
+  else if constexpr (K == 4) { float v = lo4[3] + hi4[3]; DW_PIN(v); e.e2 = v; }                  // t3
+  else if constexpr (K == 5) { float v = e.e1 + e.e2; DW_PIN(v); e.e1 = v; }                      // t2 + t3
+  else if constexpr (K == 6) { float v = e.e0 + e.e1; DW_PIN(v); e.e0 = v; }
+  else if constexpr (K == 7) { float v = real ? e.e0 : 0.f; DW_PIN(v); e.e0 = v; }                // the stage behind the last one is a re-staged copy: its rows must not reach db
+  else                       { float v = db + e.e0; DW_PIN(v); db = v; }
+}
+struct Dw88 {
+  f32x4 ran[4][2];                                     // raw A fragments of the NEXT stage
+  f32x4 rb[4][2];                                      // raw B fragments: column y takes the next stage's while column y runs
+  DwSplit sa[2][4];                                    // split A operands: [cur] this stage, [cur ^ 1] the next
+  DwSplit sb[2];                                       // split B operand of column y in sb[y & 1]; column y fills sb[(y + 1) & 1]
+  float db[4];
+  DwStream ta, tb;
+  DwSum es;
+  uint32_t voff[2][4];                                 // per-lane source offset of piece k & 3 of a stage (the same for the A and the B operand), [half of the row tile]
+  const char* ga; const char* gb;                      // wave-uniform source (row tile) of the stage being staged three ahead, A and B operand
+  uint32_t sa4, sb4;                                   // bytes per row tile of the two operands
+  int tiles_left;                                      // row tiles the source may still advance by (0: it stays on the segment's last tile - the re-stages past the end)
+  uint32_t lds0, ring;                                 // wave-uniform LDS address of piece 0 of ring slot 0; byte offset of the ring slot being staged
+  int abase, bbase, off0, off1;
+};
+// one LDS-DMA piece: 16 B per lane from s[base] + voff to LDS m0 + lane * 16 (one wait state between the m0 write and the DMA)
+// (no immediate offset: the instruction adds it to the LDS address as well as to the global one)
+template <int IMM> AF_DEV void dw_glds_s(uint32_t voff, const char* sbase, uint32_t lds) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory", "scc", "m0");
+}
+template <int CUR, int Y, int I>
+AF_DEV void dw_slot88(Dw88& q, f32x16 (&acc)[4][4], const char* nslot, bool real) {
+  constexpr int x = I & 3, p = I >> 2;
+  constexpr const int* NA = Y == 0 ? DW_NA_Z : (Y == 3 ? DW_NA_H : DW_NA_G);
+  constexpr const int* NB = Y == 0 ? DW_NB_Z : (Y == 3 ? DW_NB_H : DW_NB_G);
+  constexpr const int* LD = Y == 0 ? DW_LDS_Z : (Y == 3 ? DW_LDS_H : DW_LDS_G);
+  constexpr const int* DM = Y == 0 ? DW_DMA_Z : (Y == 3 ? DW_DMA_H : DW_DMA_G);
+  constexpr int a0 = [] { int s = 0; for (int i = 0; i < I; ++i) s += (Y == 0 ? DW_NA_Z : (Y == 3 ? DW_NA_H : DW_NA_G))[i]; return s; }();
+  constexpr int b0 = [] { int s = 0; for (int i = 0; i < I; ++i) s += (Y == 0 ? DW_NB_Z : (Y == 3 ? DW_NB_H : DW_NB_G))[i]; return s; }();
+  constexpr int na = NA[I], nb = NB[I];
+  const DwSplit& A = q.sa[CUR][x];
+  const DwSplit& B = q.sb[Y & 1];
+  // ---- the MFMA: products in the order h*l, l*h, m*m, h*m, m*h, h*h (smallest first), four output rows of tiles each
+  if constexpr (p == 0)      acc[x][Y] = dw_mfma_bf(A.h, B.l, acc[x][Y]);
+  else if constexpr (p == 1) acc[x][Y] = dw_mfma_bf(A.l, B.h, acc[x][Y]);
+  else if constexpr (p == 2) acc[x][Y] = dw_mfma_bf(A.m, B.m, acc[x][Y]);
+  else if constexpr (p == 3) acc[x][Y] = dw_mfma_bf(A.h, B.m, acc[x][Y]);
+  else if constexpr (p == 4) acc[x][Y] = dw_mfma_bf(A.m, B.h, acc[x][Y]);
+  else                       acc[x][Y] = dw_mfma_bf(A.h, B.h, acc[x][Y]);
+  // An MFMA whose result has no further use inside the loop body (the last product of a stage's last visit to its accumulator) has
+  // no successor in the block's DAG, and the instruction selector's bottom-up list scheduler then emits it - and the products in
+  // front of it on the same accumulator - at the BOTTOM of the block, below every fence: 88 MFMAs in one run.  Tie the result to the slot.
+  asm volatile("" : "+a"(acc[x][Y]));
+  __builtin_amdgcn_sched_barrier(0);                   // the MFMA leads its slot: fillers that drift in front of it leave two MFMAs back to back further down
+  if constexpr (Y == 0 && I == 0) {                    // the stage's first MFMA is in the pipe: now publish the next stage
+    dw_wait_vm<(DW_STAGES - 3) * 8>();                 // stage s+1 has landed (stage s+2 may still be in flight) ...
+    dw_barrier();                                      // ... for every wave; every wave holds what it needs of stage s-1
+  }
+  if constexpr (Y == 0 && I == 6) {                    // source / destination of the stage staged by this one (three ahead), before its first piece (slot 8)
+    // Stage n = s + 3 is half (n & 1) of row tile min(n >> 1, last): the half lives in the per-lane offset (CUR == 0 stages an odd
+    // stage, CUR == 1 an even one; a re-stage past the end may take either half), the tile advances once per two stages.
+    if constexpr (CUR == 1) {
+      const bool adv = q.tiles_left > 0;
+      q.ga += adv ? q.sa4 : 0u; q.gb += adv ? q.sb4 : 0u;
+      q.tiles_left -= 1;
+    }
+    q.ring = (q.ring + 0x8000u) & 0x18000u;
+  }
+  // ---- one raw-fragment read of the next stage
+  if constexpr (LD[I] == 1) q.ran[0][0] = *(const f32x4*)(nslot + q.abase + q.off0);
+  if constexpr (LD[I] == 2) q.ran[0][1] = *(const f32x4*)(nslot + q.abase + q.off1);
+  if constexpr (LD[I] == 3) q.rb[Y][0] = *(const f32x4*)(nslot + q.bbase + Y * 2048 + q.off0);
+  if constexpr (LD[I] == 4) q.rb[Y][1] = *(const f32x4*)(nslot + q.bbase + Y * 2048 + q.off1);
+  if constexpr (LD[I] == 5) q.ran[(Y + 1) & 3][0] = *(const f32x4*)(nslot + q.abase + ((Y + 1) & 3) * 2048 + q.off0);
+  if constexpr (LD[I] == 6) q.ran[(Y + 1) & 3][1] = *(const f32x4*)(nslot + q.abase + ((Y + 1) & 3) * 2048 + q.off1);
+  // ---- one LDS-DMA piece of the stage three ahead: column y moves pieces 2y and 2y + 1 (0..3: the A half, 4..7: the B half)
+  if constexpr (DM[I] != 0) {
+    constexpr int k = 2 * Y + DM[I] - 1;
+    dw_glds_s<k * 4096>(q.voff[CUR == 0 ? 1 : 0][k & 3], k < 4 ? q.ga : q.gb, q.lds0 + q.ring);
+  }
+  // ---- split micro-ops: A stream (fragment Y of the next stage -> sa[CUR ^ 1][Y], then its row sum -> db[Y]) and B stream
+  // (column Y + 1, or the next stage's column 0 -> sb[(Y + 1) & 1]), interleaved
+  constexpr int YN = (Y + 1) & 3;
+  auto a_op = [&](auto kc) {
+    constexpr DwAOp o = dw_aop_of(decltype(kc)::value);
+    if constexpr (o.kind == 0) dw_split_op<o.k>(q.ran[Y][0], q.ran[Y][1], q.sa[CUR ^ 1][Y], q.ta);
+    else                       dw_db_op<o.k>(q.ran[Y][0], q.ran[Y][1], q.db[Y], q.es, real);
+  };
+  auto b_op = [&](auto kc) { dw_split_op<decltype(kc)::value>(q.rb[YN][0], q.rb[YN][1], q.sb[(Y + 1) & 1], q.tb); };
+  auto both = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < na) a_op(std::integral_constant<int, a0 + j>{});
+    if constexpr (j < nb) b_op(std::integral_constant<int, b0 + j>{});
+  };
+  both(std::integral_constant<int, 0>{}); both(std::integral_constant<int, 1>{}); both(std::integral_constant<int, 2>{});
+  both(std::integral_constant<int, 3>{}); both(std::integral_constant<int, 4>{});
+  static_assert(na <= 5 && nb <= 5, "slot plan");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int CUR, int Y, int... I>
+AF_DEV void dw_col88(Dw88& q, f32x16 (&acc)[4][4], const char* nslot, bool real, std::integer_sequence<int, I...>) {
+  (dw_slot88<CUR, Y, I>(q, acc, nslot, real), ...);
+}
+
+// one segment of an 8x8 job on the slotted stage; prologue, ring and epilogue as in dw_segment_bf<8, 8, 4, 4, 6>
+AF_DEV void dw_segment_88(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane, int a0, int b0, bool store_db) {
+  constexpr int NI = 8, SLOT = NI * 4096, A_B = 8 * 2048;
+  static_assert(DW_STAGES == 4, "the slotted stage is written for the four-slot ring");
+  const int m = lane & 31, h = lane >> 5;
+  f32x16 acc[4][4];
+  Dw88 q;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    q.db[x] = 0.f;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  }
+  // piece k (0..7) of a stage: lane tid moves 16 B of feature row f = 64 (k & 3) + (tid >> 2), A half for k < 4, B half behind it;
+  // logical row group c = (tid & 3) ^ ((f >> 2) & 3) sits in physical 16-B slot tid & 3 (the bank swizzle applied on the SOURCE)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int f = 64 * k + (tid >> 2), c = (tid & 3) ^ ((f >> 2) & 3);
+    q.voff[0][k] = (uint32_t)(f * 128 + c * 16); q.voff[1][k] = q.voff[0][k] + 64u;
+  }
+  const int S = 2 * (sg.t1 - sg.t0);
+  q.lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)smem + wave * 1024);
+  q.sa4 = jb.a_stride * 4u; q.sb4 = jb.b_stride * 4u;
+  // prologue: stages 0, 1, 2 = (tile 0, half 0), (tile 0, half 1), (tile min(1, last), half 0)
+  const int ntile = sg.t1 - sg.t0;
+  q.ga = (const char*)jb.A + (size_t)sg.t0 * q.sa4; q.gb = (const char*)jb.B + (size_t)sg.t0 * q.sb4;
+  auto whole_stage = [&](int half, uint32_t ring) {
+    const uint32_t (&vo)[4] = q.voff[half];
+    dw_glds_s<0>(vo[0], q.ga, q.lds0 + ring); dw_glds_s<4096>(vo[1], q.ga, q.lds0 + ring); dw_glds_s<8192>(vo[2], q.ga, q.lds0 + ring); dw_glds_s<12288>(vo[3], q.ga, q.lds0 + ring);
+    dw_glds_s<16384>(vo[0], q.gb, q.lds0 + ring); dw_glds_s<20480>(vo[1], q.gb, q.lds0 + ring); dw_glds_s<24576>(vo[2], q.gb, q.lds0 + ring); dw_glds_s<28672>(vo[3], q.gb, q.lds0 + ring);
+  };
+  whole_stage(0, 0u);
+  whole_stage(1, 0x8000u);
+  if (ntile > 1) { q.ga += q.sa4; q.gb += q.sb4; }     // now on tile min(1, last): what stage 2 and the loop's first staged stage (3) read
+  whole_stage(0, 0x10000u);
+  q.tiles_left = ntile - 2;                            // advances left after tile 1
+  q.ring = 0x10000u;                                   // ring slot of the last stage staged (2); stage n goes to slot n & 3
+  const int sw = (m >> 2) & 3;
+  q.off0 = m * 64 + (((2 * h) ^ sw) << 4); q.off1 = m * 64 + (((2 * h + 1) ^ sw) << 4);     // rows 8h..8h+3, 8h+4..8h+7
+  q.abase = a0 * 2048; q.bbase = A_B + b0 * 2048;
+  dw_wait_vm<(DW_STAGES - 2) * NI>();                  // stage 0 has landed
+  dw_barrier();
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    q.ran[x][0] = *(const f32x4*)(smem + q.abase + x * 2048 + q.off0); q.ran[x][1] = *(const f32x4*)(smem + q.abase + x * 2048 + q.off1);
+    q.rb[x][0] = *(const f32x4*)(smem + q.bbase + x * 2048 + q.off0); q.rb[x][1] = *(const f32x4*)(smem + q.bbase + x * 2048 + q.off1);
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    q.sa[0][x] = dw_split8<3>(q.ran[x][0], q.ran[x][1]);
+    const f32x4 t = q.ran[x][0] + q.ran[x][1];
+    q.db[x] += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  q.sb[0] = dw_split8<3>(q.rb[0][0], q.rb[0][1]);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s = 0; s < S; s += 2) {                      // S is even (two stages per 32-row tile)
+    {
+      const char* nslot = smem + ((s + 1) % DW_STAGES) * SLOT;
+      const bool real = s + 1 < S;
+      dw_col88<0, 0>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<0, 1>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<0, 2>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<0, 3>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+    }
+    {
+      const char* nslot = smem + ((s + 2) % DW_STAGES) * SLOT;      // past the last stage: harmless reads of a re-staged slot
+      const bool real = s + 2 < S;
+      dw_col88<1, 0>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<1, 1>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<1, 2>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+      dw_col88<1, 3>(q, acc, nslot, real, std::make_integer_sequence<int, 24>{});
+    }
+  }
+  dw_wait_vm<0>();
+  dw_barrier();
+
+  float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
+  constexpr int pld = 8 * 32;
+  const auto rblk = af_rsrc_uniform(blk, jb.part_blk * 4);
+  const int voff = ((a0 * 32 + 4 * h) * pld + b0 * 32 + m) * 4;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        af_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const float tot = q.db[x] + __shfl_xor(q.db[x], 32);
+    if (store_db && h == 0) af_bs32(tot, rblk, (8 * 32 * pld + a0 * 32 + m) * 4, x * 128);
+  }
+}
+
 template <int TO, int TI, int TOW, int TIW, int NPROD = 6>
 AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char* smem, int tid, int wave, int lane,
                           int a0, int b0, bool store_w, bool store_db) {
@@ -219,11 +490,18 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     sel_a[k] = is_a;
   }
   const int S = 2 * (sg.t1 - sg.t0);
+  // The source of a piece = a wave-uniform stage base (SGPR pair, made opaque so that hipcc does not re-associate it into the
+  // per-lane part) + the lane's 32-bit offset: the `global_load_lds_dwordx4 voff, s[base]` form, no 64-bit VALU address per piece.
+  auto sgpr = [](const char* p) {
+    uint32_t lo = (uint32_t)(uint64_t)p, hi = (uint32_t)((uint64_t)p >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+  };
   auto issue = [&](int s, int k) {
     const int sc = s < S ? s : S - 1;
     const size_t t = (size_t)(sg.t0 + (sc >> 1));
-    const char* ga = (const char*)jb.A + t * jb.a_stride * 4u + (sc & 1) * 64;      // wave-uniform
-    const char* gb = (const char*)jb.B + t * jb.b_stride * 4u + (sc & 1) * 64;
+    const char* ga = sgpr((const char*)jb.A + t * jb.a_stride * 4u + (sc & 1) * 64);      // wave-uniform
+    const char* gb = sgpr((const char*)jb.B + t * jb.b_stride * 4u + (sc & 1) * 64);
     const bool all_a = (k + 1) * 256 <= TO * 128, all_b = k * 256 >= TO * 128 && (k + 1) * 256 <= NP;
     const char* g = all_a ? ga : (all_b ? gb : (sel_a[k] ? ga : gb));
     af_glds16(g + soff[k], smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
@@ -415,13 +693,36 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
 // left there.  Clip the segment to the live tiles; a segment with nothing left stores the zero block k_adam expects in its slot.
 AF_DEV bool dw_clip(const DwJob& jb, DwSeg& sg, float* partial, int tid) {
   if (!jb.live_rows) return true;
-  const int nt = (jb.live_base + *jb.live_rows + 31) >> 5;
+  // (the count comes through a vector load: without the readfirstlane the segment's tile range — and with it every address of the
+  // operand stream — is computed per lane, ~30 VALU instructions per stage that compete with the split for the MFMAs' shadows)
+  const int nt = __builtin_amdgcn_readfirstlane((jb.live_base + *jb.live_rows + 31) >> 5);
   if (sg.t1 > nt) sg.t1 = nt;
   if (sg.t0 < sg.t1) return true;
   float* blk = partial + jb.part_off + (size_t)sg.slot * jb.part_blk;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   for (uint32_t i = (uint32_t)tid * 4u; i < jb.part_blk; i += 1024u) *(f32x4*)(blk + i) = z;
   return false;
+}
+
+// Segment and job descriptors are read after the previous segment's stores, so hipcc fetches them with VECTOR loads (the scalar
+// cache is not coherent with them) and every address derived from them — the operand stream's source pointers above all — is then
+// computed per lane.  They are wave-uniform by construction: pin them to SGPRs.
+template <class T> AF_DEV T* dw_uniform_ptr(T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));      // (the builtin returns int: no sign extension into the high word)
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+AF_DEV DwSeg dw_uniform(const DwSeg& g) {
+  return DwSeg{__builtin_amdgcn_readfirstlane(g.job), __builtin_amdgcn_readfirstlane(g.t0), __builtin_amdgcn_readfirstlane(g.t1), __builtin_amdgcn_readfirstlane(g.slot)};
+}
+AF_DEV DwJob dw_uniform(const DwJob& j) {
+  DwJob u;
+  u.A = dw_uniform_ptr(j.A); u.B = dw_uniform_ptr(j.B);
+  u.a_stride = (uint32_t)__builtin_amdgcn_readfirstlane(j.a_stride); u.b_stride = (uint32_t)__builtin_amdgcn_readfirstlane(j.b_stride);
+  u.shape = __builtin_amdgcn_readfirstlane(j.shape);
+  u.part_off = (uint32_t)__builtin_amdgcn_readfirstlane(j.part_off); u.part_blk = (uint32_t)__builtin_amdgcn_readfirstlane(j.part_blk);
+  u.live_base = __builtin_amdgcn_readfirstlane(j.live_base); u.live_rows = dw_uniform_ptr(j.live_rows);
+  return u;
 }
 
 template <int NPROD>
@@ -437,12 +738,15 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int s = 0; s < DW_MAXSEG; ++s) {
-    DwSeg sg = segs[s];
+    DwSeg sg = dw_uniform(segs[s]);
     if (sg.job < 0) break;
-    const DwJob jb = a.jobs[sg.job];
+    const DwJob jb = dw_uniform(a.jobs[sg.job]);
     if (!dw_clip(jb, sg, a.partial, tid)) continue;
     switch (jb.shape) {      // 8x8: each wave a 4x4 block of output tiles (8 operand tiles to read and split per stage, the minimum)
-      case DW_8x8: dw_segment_bf<8, 8, 4, 4, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2); break;
+      case DW_8x8:
+        if constexpr (DW_SLOT && NPROD == 6 && !DW_ABL) dw_segment_88(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), wave < 2);
+        else dw_segment_bf<8, 8, 4, 4, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 4 * (wave & 1), 4 * (wave >> 1), true, wave < 2);
+        break;
       case DW_8x2: dw_segment_bf<8, 2, 2, 2, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
       case DW_8x1: dw_segment_bf<8, 1, 2, 1, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 2 * wave, 0, true, true); break;
       case DW_1x8: dw_segment_bf<1, 8, 1, 2, NPROD>(jb, sg, a.partial, smem, tid, wave, lane, 0, 2 * wave, true, wave == 0); break;

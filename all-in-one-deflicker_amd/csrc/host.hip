@@ -308,9 +308,18 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   // narrow shapes (layer 0, skip columns, output layer) are bound by the latency of their 36-40 KB operand tiles, so they do not
   // get cheaper when the 8x8 tiles move to the bf16 matrix pipe:
   //   fp32 MFMA k_dw:  8x8 7.9 us/tile, 8x2 2.4, 8x1 1.6, 1x8 1.6, 1x2 1.2      bf16x6 k_dw_bf:  8x8 5.47, 8x2 2.0, 8x1 1.44, 1x8 1.44, 1x2 0.9
-  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 133.0, 113.0, 108.0, 72.0}, {306.0, 168.0, 157.0, 150.0, 95.0}};     // rows 1, 2 re-fitted in round 3 for the software-pipelined k_dw_bf (gpurun_out/r3g_dwfit_m*.txt)
-  const double seg_cost = 60.0;
-  auto tile_cost = [&](int j) { return kTileCost[h->dw_mode][sc.jobs[j].shape]; };
+  // Row 1 re-fitted in round 4 for the slotted 8x8 stage (dw.hip DW_SLOT: the 8x8 tile got 13 % cheaper in ticks, the narrow shapes did not):
+  // non-negative least squares over 1024 workgroups (tools/dw_fit.py --save, gpurun_out/r4f_dwfit_sys.npz): 8x8 4.0-4.3 us per tile, ratios
+  // 306 : 158 : 133 : 136 : 92 on the single- and the two-layer schedules alike; with the stale row the slowest workgroup ran 15 % over the mean.
+  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 158.0, 133.0, 136.0, 92.0}, {306.0, 168.0, 157.0, 150.0, 95.0}};     // row 2 fitted in round 3 (gpurun_out/r3g_dwfit_m2.txt)
+  double seg_cost = 60.0;
+  double cost_row[5];
+  for (int i = 0; i < 5; ++i) cost_row[i] = kTileCost[h->dw_mode][i];
+  if (const char* e_ = getenv("AF_DW_COST")) {     // experiments only (tools/dw_cost_sweep.sh): "c8x8,c8x2,c8x1,c1x8,c1x2[,seg]" replaces the row of the current arithmetic
+    double v_[6]; const int n_ = sscanf(e_, "%lf,%lf,%lf,%lf,%lf,%lf", v_, v_ + 1, v_ + 2, v_ + 3, v_ + 4, v_ + 5);
+    if (n_ >= 5) { for (int i = 0; i < 5; ++i) cost_row[i] = v_[i]; if (n_ == 6) seg_cost = v_[5]; }
+  }
+  auto tile_cost = [&](int j) { return cost_row[sc.jobs[j].shape]; };
   double work = 0;
   for (int j = 0; j < nj; ++j) work += tile_cost(j) * job_nt[j];
   int nwg = (int)std::min<double>(h->ncu, std::max(1.0, work / (4.0 * 276.0)));     // at least ~4 full-size row tiles per workgroup

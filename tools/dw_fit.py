@@ -34,6 +34,8 @@ for two in (False, True):
         print("two_layer", two, "schedule", which, "span mean %.1f max %.1f us" % (dur.mean(), dur.max()))
     af.close()
 A, b = np.array(rows), np.array(rhs)
+if "--save" in sys.argv:      # the raw system (per workgroup: tiles per shape, segments per shape | busy us) for offline fits
+    np.savez(sys.argv[sys.argv.index("--save") + 1], A=A, b=b)
 sol, res, rank, sv = np.linalg.lstsq(A, b, rcond=None)
 unit = sol[0] / 256.0
 names = ("8x8", "8x2", "8x1", "1x8", "1x2")

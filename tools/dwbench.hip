@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <math.h>
+#include <algorithm>
 #include "../all-in-one-deflicker_amd/csrc/dw.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main(int argc, char** argv) {
@@ -48,7 +50,18 @@ int main(int argc, char** argv) {
              "(workgroup span %.1f us mean, first start to last end %.1f us, launch %.1f us)\n", tk, tk / (2 * per), tk / (ms * 1000), tk / (rt / 100.0), rt / 100.0, (last - first) / 100.0, ms * 1000);
     }
 #endif
-    printf("DW_ABL=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, cached ? " L2-resident" : "", mode, mode == 2 ? "bf16x3" : (mode ? "bf16x6" : "fp32 MFMA"), per, ms, fl / ms / 1e9, by / ms / 1e9);
+    printf("DW_ABL=%d DW_SLOT=%d%s mode %d (%s) %d tiles/WG: %.4f ms  %.1f TF-equivalent  %.2f TB/s\n", DW_ABL, DW_SLOT, cached ? " L2-resident" : "", mode, mode == 2 ? "bf16x3" : (mode ? "bf16x6" : "fp32 MFMA"), per, ms, fl / ms / 1e9, by / ms / 1e9);
+    {   // FNV-1a over the bits of every partial block: the slotted stage (DW_SLOT=1) keeps the compiler-scheduled kernel's MFMA order, so the two
+        // builds must print the same hash for mode 1; against mode 0 (fp32 MFMA) the blocks agree to fp32 round-off (max relative distance printed)
+      std::vector<uint32_t> hp((size_t)nwg * (65536 + 256)); CK(hipMemcpy(hp.data(), partial, hp.size() * 4, hipMemcpyDeviceToHost));
+      unsigned long long hsh = 1469598103934665603ull; for (uint32_t w : hp) { hsh ^= w; hsh *= 1099511628211ull; }
+      static std::vector<float> ref;
+      double worst = 0, scale = 0;
+      if (mode == 0) ref.assign((float*)hp.data(), (float*)hp.data() + hp.size());
+      else { for (size_t i = 0; i < hp.size(); ++i) { const float v = ((float*)hp.data())[i]; worst = std::max(worst, (double)fabsf(v - ref[i])); scale = std::max(scale, (double)fabsf(ref[i])); } }
+      printf("   partial blocks: hash %016llx%s", hsh, mode ? "" : "\n");
+      if (mode) printf("  max |x - fp32 MFMA| / max |fp32 MFMA| = %.3g\n", worst / scale);
+    }
   }
   return 0;
 }
