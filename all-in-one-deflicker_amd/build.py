@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libatlasfit.so")
 UNITS = ["mlp.hip", "mlpbf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
-HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", os.path.join("..", "..", "include", "atlasfit.h")]
+HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", "dw_slots.h", os.path.join("..", "..", "include", "atlasfit.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("AF_HIPCC_EXTRA", "").split()     # AF_HIPCC_EXTRA: -D switches of the kernel experiments (tools/experiments/README.md); use with --force
 
 
@@ -26,6 +26,14 @@ def _check_no_scratch(name, stderr):
             bad.append((cur, int(m.group(1))))
     if bad and not os.environ.get("AF_ALLOW_SCRATCH"):
         raise RuntimeError("%s: kernels with scratch (spilled registers): %s" % (name, bad))
+
+
+def _isa_check():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("af_isa_check", os.path.join(HERE, "isa_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def _hipcc():
@@ -62,6 +70,7 @@ def build(force=False, verbose=True):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr))
         _check_no_scratch(name, r.stderr)
+        _isa_check().check_unit(name, cmd[-1], verbose=verbose)      # ISA invariants of the hand-scheduled kernels (isa_check.py): fail the build, not the run
         if verbose and ("warning:" in r.stderr or "error:" in r.stderr):      # the resource-usage remarks alone are not worth printing
             print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l))
 

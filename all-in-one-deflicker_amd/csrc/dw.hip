@@ -281,10 +281,14 @@ struct Dw88 {
   int abase, bbase, off0, off1;
 };
 // one LDS-DMA piece: 16 B per lane from s[base] + voff to LDS m0 + lane * 16 (one wait state between the m0 write and the DMA)
-// (no immediate offset: the instruction adds it to the LDS address as well as to the global one)
+// (no immediate offset: the instruction adds it to the LDS address as well as to the global one; m0 is named as clobbered on purpose —
+// hipcc keeps its own LDS-DMA destinations there in the other job shapes — which clang flags as a reserved register)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <int IMM> AF_DEV void dw_glds_s(uint32_t voff, const char* sbase, uint32_t lds) {
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory", "scc", "m0");
 }
+#pragma clang diagnostic pop
 template <int CUR, int Y, int I>
 AF_DEV void dw_slot88(Dw88& q, f32x16 (&acc)[4][4], const char* nslot, bool real) {
   constexpr int x = I & 3, p = I >> 2;

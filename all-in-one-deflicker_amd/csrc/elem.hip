@@ -631,8 +631,31 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     float p = a.bufs.params[pidx];
     if (UPDATE) {
       const float* pp = a.partial + j.part_off + (is_bias ? j.out_real_pad * j.pld + o : o * j.pld + i);
+      // split-K reduction in slot order (fixed: runs are bit-reproducible).  Eight loads in flight per thread: written as a plain loop
+      // hipcc emits load / s_waitcnt vmcnt(0) / add per slot - ~25 serial round trips to the partial blocks k_dw has just written, which
+      // was the whole 29 us of this kernel (profiles/r3_trace.txt).
       float g = 0.f;
-      for (uint32_t s = 0; s < j.nslots; ++s) g += pp[(size_t)s * j.part_blk];
+      uint32_t s = 0;
+      for (; s + 8 <= j.nslots; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = pp[(size_t)(s + q) * j.part_blk];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g += t[q];
+      }
+      if (s + 4 <= j.nslots) {
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = pp[(size_t)(s + q) * j.part_blk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g += t[q];
+        s += 4;
+      }
+      if (s + 2 <= j.nslots) {
+        const float t0 = pp[(size_t)s * j.part_blk], t1 = pp[(size_t)(s + 1) * j.part_blk];
+        g += t0; g += t1; s += 2;
+      }
+      if (s < j.nslots) g += pp[(size_t)s * j.part_blk];
       float m = a.bufs.m[pidx], v = a.bufs.v[pidx];
       m = m + (g - m) * a.hy.one_minus_b1;
       v = v * a.hy.beta2 + (a.hy.one_minus_b2 * g) * g;

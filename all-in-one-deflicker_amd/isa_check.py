@@ -1,0 +1,163 @@
+"""ISA invariants of the hand-scheduled kernels, asserted on the disassembly of every build (build.py calls check_unit after hipcc).
+
+The chains (mlpbf.hip) and the slotted k_dw_bf<6> stage (dw.hip) rely on instruction ORDER that hipcc does not know about: fragment
+reads issued by inline asm straight into AGPRs (invisible to the compiler's s_waitcnt insertion), LDS-DMA pieces whose arrival is
+published by a COUNTED `s_waitcnt vmcnt(16)` that assumes exactly the 16 tile stores of a k-step are younger than the last piece,
+MFMAs tied to issue slots.  A later edit or a compiler upgrade that re-orders them corrupts results silently or loses the schedule;
+round 3 met both.  Here the build fails instead:
+
+  mlpbf.o  (a) every `ds_read_b128 a[..]` is followed by an `s_waitcnt` with lgkmcnt(0) before the first v_mfma that reads that AGPR;
+           (b) between the last `global_load_lds` and each `s_waitcnt vmcnt(16)` lie exactly 16 buffer_store_dword and no other
+               vector-memory instruction;
+  dw.o     (c) the main loop of k_dw_bf<6> holds 192 MFMAs (two slotted 8x8 stages), never more than two back to back, two counted
+               `s_waitcnt vmcnt(8)` + `s_barrier`, and 16 LDS-DMA pieces each directly behind its m0 write and one wait state;
+  every unit: no scratch_ instruction (build.py's remark check, restated on the disassembly).
+"""
+import os
+import re
+import subprocess
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def disassemble(obj):
+    """Device ISA of a hipcc object: {kernel symbol: [instruction text, ...]} (llvm-objdump --offloading writes the bundles next to the object)."""
+    d = os.path.dirname(os.path.abspath(obj))
+    base = os.path.basename(obj)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", base], cwd=d, check=True, capture_output=True)
+    co = [f for f in os.listdir(d) if f.startswith(base + ".") and f.endswith(TARGET)]
+    assert len(co) == 1, (obj, co)
+    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(d, co[0])], check=True, capture_output=True, text=True).stdout
+    for f in os.listdir(d):
+        if f.startswith(base + "."):
+            os.remove(os.path.join(d, f))
+    kernels, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+            continue
+        if cur is not None and line.startswith("\t"):
+            cur.append(line.split("//")[0].strip())
+    return kernels
+
+
+def _regs(tok):
+    m = re.match(r"([av])\[(\d+):(\d+)\]", tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.match(r"([av])(\d+)$", tok)
+    if m:
+        return m.group(1), {int(m.group(2))}
+    return None, set()
+
+
+def check_agpr_fragment_reads(name, ins):
+    """(a) asm ds_read_b128 into AGPRs: waited for (lgkmcnt(0)) before an MFMA reads them."""
+    pending = {}                      # AGPR -> index of the read that has not been waited for
+    n = 0
+    for i, s in enumerate(ins):
+        op = s.split()[0]
+        if op == "ds_read_b128" and s.split()[1].startswith("a["):
+            _, regs = _regs(s.split()[1].rstrip(","))
+            for r in regs:
+                pending[r] = i
+            n += 1
+        elif op == "s_waitcnt" and "lgkmcnt(0)" in s:
+            pending.clear()
+        elif op.startswith("v_mfma") and pending:
+            toks = [t.strip().rstrip(",") for t in s.split(None, 1)[1].split(",")]
+            for t in toks[1:3]:                        # srcA, srcB
+                kind, regs = _regs(t)
+                hit = [r for r in regs if kind == "a" and r in pending]
+                if hit:
+                    raise RuntimeError("%s: %r reads a%d, loaded by the asm ds_read at instruction %d, with no s_waitcnt lgkmcnt(0) in between"
+                                       % (name, s, hit[0], pending[hit[0]]))
+    return n
+
+
+def check_counted_publish(name, ins, keep=16):
+    """(b) the publish's counted vmcnt: exactly `keep` tile stores, and nothing else on the vector-memory counter, behind the last DMA piece."""
+    n = 0
+    for i, s in enumerate(ins):
+        if s.startswith("s_waitcnt") and "vmcnt(%d)" % keep in s:
+            stores = other = 0
+            j = i - 1
+            while j >= 0 and not ins[j].startswith("global_load_lds"):
+                op = ins[j].split()[0]
+                if op.startswith("buffer_store_dword") and not op.startswith("buffer_store_dwordx"):
+                    stores += 1
+                elif op.startswith(("buffer_", "global_", "flat_", "scratch_")):
+                    other += 1
+                j -= 1
+            if j < 0 or stores != keep or other:
+                raise RuntimeError("%s: s_waitcnt vmcnt(%d) at instruction %d has %d tile stores and %d other vector-memory instructions behind the last LDS-DMA piece"
+                                   % (name, keep, i, stores, other))
+            n += 1
+    return n
+
+
+def check_dw_slots(name, ins):
+    """(c) the slotted 8x8 loop of k_dw_bf<6>: the branch-free stretch with exactly the 192 MFMAs of two stages."""
+    idx = [i for i, s in enumerate(ins) if s.startswith("s_cbranch")]
+    best = None
+    for a, b in zip(idx, idx[1:]):
+        if sum(1 for s in ins[a:b] if s.startswith("v_mfma")) == 192:
+            best = (a, b)
+    if best is None:
+        raise RuntimeError("%s: no branch-free stretch with the 192 MFMAs of two slotted 8x8 stages" % name)
+    body = ins[best[0] + 1:best[1]]
+    run = worst = 0
+    for s in body:
+        if s.startswith("v_mfma"):
+            run += 1
+        elif not s.startswith("s_nop"):
+            run = 0
+        worst = max(worst, run)
+    if worst > 2:
+        raise RuntimeError("%s: %d MFMAs back to back in the slotted loop (every MFMA leads its own slot of fillers)" % (name, worst))
+    if sum(1 for s in body if s.startswith("s_waitcnt") and "vmcnt(8)" in s) != 2 or sum(1 for s in body if s == "s_barrier") != 2:
+        raise RuntimeError("%s: the slotted loop must hold one counted vmcnt(8) wait and one s_barrier per stage" % name)
+    dma = [i for i, s in enumerate(body) if s.startswith("global_load_lds_dwordx4")]
+    if len(dma) != 16:
+        raise RuntimeError("%s: %d LDS-DMA pieces in the slotted loop, expected 16" % (name, len(dma)))
+    for i in dma:
+        if not (body[i - 1].startswith("s_nop") and body[i - 2].startswith("s_add_u32 m0")) or body[i].rstrip().endswith(" off"):
+            raise RuntimeError("%s: LDS-DMA piece %r not in the `s_add_u32 m0 / s_nop / global_load_lds voff, s[base]` form" % (name, body[i - 2:i + 1]))
+    fill = [0]
+    for s in body:
+        if s.startswith("v_mfma"):
+            fill.append(0)
+        else:
+            fill[-1] += 1
+    return max(fill[1:-1]), (sum(fill[1:-1]) / float(len(fill) - 2))
+
+
+def check_unit(unit, obj, verbose=True):
+    ks = disassemble(obj)
+    for name, ins in ks.items():
+        if any(s.startswith("scratch_") for s in ins):
+            raise RuntimeError("%s: %s uses scratch memory" % (unit, name))
+    msg = []
+    if unit == "mlpbf.hip":
+        na = sum(check_agpr_fragment_reads(n, i) for n, i in ks.items())
+        nb = sum(check_counted_publish(n, i) for n, i in ks.items())
+        if na == 0 or nb == 0:
+            raise RuntimeError("mlpbf.hip: the checks found nothing to check (%d AGPR fragment reads, %d counted publishes): the patterns moved" % (na, nb))
+        msg.append("%d asm fragment reads waited for, %d counted publishes with exactly 16 stores behind the last DMA piece" % (na, nb))
+    if unit == "dw.hip" and "-DDW_SLOT=0" not in os.environ.get("AF_HIPCC_EXTRA", ""):
+        k = [n for n in ks if "k_dw_bf" in n and "Li6E" in n]
+        assert len(k) == 1, list(ks)
+        worst, mean = check_dw_slots(k[0], ks[k[0]])
+        msg.append("slotted k_dw_bf<6> loop: 192 MFMAs, at most %d fillers in a slot, %.2f on average" % (worst, mean))
+    if verbose and msg:
+        print("[isa] %s: %s" % (unit, "; ".join(msg)), flush=True)
+    return msg
+
+
+if __name__ == "__main__":
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for u in sys.argv[1:] or ["mlpbf.hip", "dw.hip", "mlp.hip", "mlp16.hip", "elem.hip"]:
+        check_unit(u, os.path.join(here, "build", u.replace(".hip", ".o")))

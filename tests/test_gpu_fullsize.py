@@ -281,8 +281,17 @@ def test_full_size_is_bit_reproducible_and_finite(full):
     assert (outs[0][0][:, 6] <= 10000).all() and (outs[0][0][:, 6] > 9000).all()  # ~1/80 of the samples sit on the last frame
 
 
-@pytest.mark.parametrize("two_layer", [False, True])
-def test_long_run_is_bit_reproducible(two_layer):
+# the architectures that broke in round 3 (a two-layer net's chain, gpurun_out/r3k_pytest.log) next to the shipped one: a 2-layer mapping
+# net (the loop-free copy of the chain), a mapping net with positional encoding, a 5-layer atlas net with the skip on its OUTPUT layer,
+# a 2-layer second mapping net and a 3-layer alpha net in the four-net plan
+ARCHS = [(False, None), (True, None),
+         (False, dict(number_of_layers_mapping1=2, number_of_layers_atlas=5)),
+         (False, dict(use_positional_encoding_mapping1=True, number_of_positional_encoding_mapping1=4, number_of_layers_mapping1=3)),
+         (True, dict(number_of_layers_mapping1=2, number_of_layers_mapping2=2, number_of_layers_alpha=3, number_of_layers_atlas=5))]
+
+
+@pytest.mark.parametrize("two_layer,arch", ARCHS)
+def test_long_run_is_bit_reproducible(two_layer, arch):
     """The chains hand LDS chunks over on a COUNTED vmcnt (tile stores stay in flight behind the DMA pieces they follow) and read
     their weight fragments through asm the compiler's wait insertion cannot see (mlpbf.hip, round 3): a mistake there would show
     as a rare, timing-dependent stale tile.  600 consecutive iterations at full size (both row regimes, device sampler) twice from
@@ -296,12 +305,27 @@ def test_long_run_is_bit_reproducible(two_layer):
     video = bench.synth_video_device(resx, resy, F, seed=4, device=dev, flow="field")
     if two_layer:
         video = video + (bench.synth_fg_mask_device(resx, resy, F, seed=4, device=dev),)
-    sds = bench.init_state_dicts(99, two_layer)
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    cfg.update(arch or {})
+    iters = 600 if arch is None else 300
 
     def handle():
-        h = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=two_layer))
+        h = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, cfg, two_layer=two_layer))
         h.upload_video(*video)
         return h
+
+    def state_dicts(h):      # torch default nn.Linear init in construction order for THIS architecture's layer shapes
+        torch.manual_seed(99)
+        sds = {}
+        for net in h.nets:
+            sd = {}
+            for i, (o, k) in enumerate(aiod_amd.atlasfit.imlp_shapes(net, h.cfg)):
+                lin = torch.nn.Linear(k, o)
+                sd["hidden.%d.weight" % i] = lin.weight.detach(); sd["hidden.%d.bias" % i] = lin.bias.detach()
+            sds[net] = sd
+        return sds
+
+    sds = None
 
     def run(h):
         for net in h.nets:
@@ -311,9 +335,10 @@ def test_long_run_is_bit_reproducible(two_layer):
         h.pre_train_mapping(1, seed=5)
         if two_layer:
             h.pre_train_mapping(1, seed=6, net=aiod_amd.NET_MAPPING2)
-        losses = h.train_steps(4700, 600, None, seed=21)
+        losses = h.train_steps(5001 - iters // 2, iters, None, seed=21)
         return losses, [h.get_params_flat(net) for net in h.nets]
     af = handle()
+    sds = bench.init_state_dicts(99, two_layer) if arch is None else state_dicts(af)
     a = run(af)
     b = run(af)
     other = handle()
