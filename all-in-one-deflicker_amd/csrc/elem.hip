@@ -631,9 +631,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     float p = a.bufs.params[pidx];
     if (UPDATE) {
       const float* pp = a.partial + j.part_off + (is_bias ? j.out_real_pad * j.pld + o : o * j.pld + i);
-      // split-K reduction in slot order (fixed: runs are bit-reproducible).  Eight loads in flight per thread: written as a plain loop
-      // hipcc emits load / s_waitcnt vmcnt(0) / add per slot - ~25 serial round trips to the partial blocks k_dw has just written, which
-      // was the whole 29 us of this kernel (profiles/r3_trace.txt).
+      // split-K reduction in slot order (fixed: runs are bit-reproducible).  Eight loads in flight per thread (as a plain loop hipcc emits
+      // load / s_waitcnt vmcnt(0) / add per slot).  Measured (round 4, rocprofv3): 29.1 -> 30.6 us, i.e. nothing: with ~5 500 blocks in
+      // flight the latency was already hidden across waves; the kernel moves the 66 MB of partial blocks k_dw has just written plus
+      // ~35 MB of state and weight views, ~3.3 TB/s - it is bound by the partial volume (one 257 KB block per k_dw workgroup).
       float g = 0.f;
       uint32_t s = 0;
       for (; s + 8 <= j.nslots; s += 8) {

@@ -311,7 +311,9 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   // Row 1 re-fitted in round 4 for the slotted 8x8 stage (dw.hip DW_SLOT: the 8x8 tile got 13 % cheaper in ticks, the narrow shapes did not):
   // non-negative least squares over 1024 workgroups (tools/dw_fit.py --save, gpurun_out/r4f_dwfit_sys.npz): 8x8 4.0-4.3 us per tile, ratios
   // 306 : 158 : 133 : 136 : 92 on the single- and the two-layer schedules alike; with the stale row the slowest workgroup ran 15 % over the mean.
-  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 158.0, 133.0, 136.0, 92.0}, {306.0, 168.0, 157.0, 150.0, 95.0}};     // row 2 fitted in round 3 (gpurun_out/r3g_dwfit_m2.txt)
+  // A sweep on the real step (tools/dw_cost_sweep.sh, gpurun_out/r4e/r4f/r4i_sweep.txt) prefers the narrow shapes another 5 % dearer: per-workgroup
+  // busy mean / max 0.95 (9 segments) and 0.92 (7 segments).
+  static const double kTileCost[3][5] = {{306.0, 94.0, 62.0, 62.0, 46.0}, {306.0, 166.0, 140.0, 143.0, 97.0}, {306.0, 168.0, 157.0, 150.0, 95.0}};     // row 2 fitted in round 3 (gpurun_out/r3g_dwfit_m2.txt)
   double seg_cost = 60.0;
   double cost_row[5];
   for (int i = 0; i < 5; ++i) cost_row[i] = kTileCost[h->dw_mode][i];
