@@ -27,6 +27,11 @@ def disassemble(obj):
     base = os.path.basename(obj)
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", base], cwd=d, check=True, capture_output=True)
     co = [f for f in os.listdir(d) if f.startswith(base + ".") and f.endswith(TARGET)]
+    if not co:                        # a unit without device code (host.hip)
+        for f in os.listdir(d):
+            if f.startswith(base + "."):
+                os.remove(os.path.join(d, f))
+        return {}
     assert len(co) == 1, (obj, co)
     txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(d, co[0])], check=True, capture_output=True, text=True).stdout
     for f in os.listdir(d):
