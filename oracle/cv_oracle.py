@@ -145,5 +145,5 @@ def cv_compute_consistency(flow12, flow21):
     for y in range(h):
         for x in range(w):
             du = F32(flow12[y, x, 0] + warped[y, x, 0]); dv = F32(flow12[y, x, 1] + warped[y, x, 1])
-            out[y, x] = F32(F32(F32(du * du) + F32(dv * dv)) ** F32(0.5))
+            out[y, x] = np.sqrt(F32(F32(du * du) + F32(dv * dv)))      # numpy evaluates `array ** .5` as a correctly rounded sqrt (a scalar `**` goes through powf)
     return out
