@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "af_get_params", "af_get_adam_state", "af_set_adam_state", "af_pretrain", "af_train_steps",
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
-    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
+    "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_debug_step_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
 ]
 
 
@@ -171,6 +171,7 @@ def load_library(path=None):
         "af_resize_bilinear": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i64, C.c_double, C.c_double, i32]),
         "af_flow_consistency": (i32, [i32, vp, vp, i32, i32, vp, i64, i64, C.c_float, i32]),
         "af_debug_dw_clocks": (i32, [vp, i32, vp, i32]),
+        "af_debug_step_clocks": (i32, [vp, i32, vp, i32]),
         "af_debug_dw_schedule": (i32, [vp, i32, vp, i32]),
         "af_set_dw_mode": (i32, [vp, i32]),
         "af_set_mlp_mode": (i32, [vp, i32]),
@@ -421,6 +422,17 @@ class AtlasFit:
         if n < 0:
             self._chk(n)
         return out[:n]
+
+    STEP_CLOCK_LAUNCHES = ("fwd_1", "fwd_2", "bwd_1", "bwd_2", "dw")
+
+    def step_clocks(self, enable=True):
+        """{launch: (#workgroups, 4) uint64 = s_memrealtime (100 MHz), s_memtime (shader clock) at workgroup start, then at its end} of
+        the most recent training step for the five hot launches (include/atlasfit.h: af_debug_step_clocks); the first call enables the stamps."""
+        out = np.zeros((5, 4096, 4), np.uint64)
+        n = self.lib.af_debug_step_clocks(self.h, int(enable), _ptr(out), 4096)
+        if n < 0:
+            self._chk(n)
+        return {name: out[i][out[i, :, 2] > 0] for i, name in enumerate(self.STEP_CLOCK_LAUNCHES)}
 
     def dw_schedule(self, which):
         """(#workgroups, 16, 4) int32 segments {shape, t0, t1, job} of k_dw's static schedule `which` (0: 9 segments, 1: 7)."""

@@ -83,8 +83,9 @@ struct BwdArgs {
 };
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip
-struct MultiFwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; FwdArgs a[AF_MAX_NETS]; };
-struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; int nprod; };      // nprod: 3 selects the three-product chain (mlpbf.hip)
+// wg_stamp (optional, af_debug_step_clocks): [gridDim.x][4] = s_memrealtime (100 MHz) and s_memtime (shader clock) at workgroup start, then at its end
+struct MultiFwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; FwdArgs a[AF_MAX_NETS]; unsigned long long* wg_stamp; };
+struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; int nprod; unsigned long long* wg_stamp; };      // nprod: 3 selects the three-product chain (mlpbf.hip)
 
 struct DwJob {
   const float* A; const float* B;     // T-layout tensors (dZ_l and X_l)
@@ -101,6 +102,7 @@ struct DwArgs {
   const DwJob* jobs; const DwSeg* segs;   // segs: [gridDim.x][DW_MAXSEG], job<0 terminates
   float* partial;
   unsigned long long* wg_clock;           // optional [gridDim.x][2]: s_memrealtime at workgroup start / end (balance diagnostics)
+  unsigned long long* wg_stamp;           // optional [gridDim.x][4]: as in MultiFwd (the clock the kernel runs at inside the real step)
 };
 
 #if defined(__HIPCC__)

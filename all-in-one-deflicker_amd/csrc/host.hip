@@ -110,6 +110,7 @@ struct af_handle {
   // schedules: 0 = 9 segments, 1 = 7 segments, 2 = pretrain mapping1, 3 = pretrain mapping2
   Sched sched[4]; float* partial = nullptr; size_t partial_cap = 0;
   unsigned long long* dw_clock = nullptr;     // af_debug_dw_clocks: per-workgroup start/end times of the last k_dw launch
+  unsigned long long* step_stamp = nullptr;   // af_debug_step_clocks: [5 launches: fwd_1, fwd_2, bwd_1, bwd_2, dw][AF_STAMP_WG][4] of the last step
   // render
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
@@ -495,6 +496,7 @@ bool glob_on(const af_config& c, int iter) { return c.include_global_rigidity_lo
 // rows of a part that carry real data (the last tile of a net may be padded)
 double part_rows(int tile0, int NT, int rows_total) { return (double)std::max(0, std::min(NT * 32, rows_total) - tile0 * 32); }
 
+#define AF_STAMP_WG 4096      // workgroups per launch the stamp buffer holds (a launch of the shipped sizes has at most ~1200)
 struct FwdPart { int net; FwdArgs a; int rows_total; };
 struct BwdPart { int net; BwdArgs a; int rows_total; };
 
@@ -507,6 +509,7 @@ int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool
     fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_fwd[p.net];
   }
   if (m.n == 0) return 0;
+  if (h->step_stamp && train && (cls == T_FWD_1 || cls == T_FWD_2)) m.wg_stamp = h->step_stamp + (size_t)(cls == T_FWD_1 ? 0 : 1) * AF_STAMP_WG * 4;
   Timer t(h, cls, fl);
   if (h->mlp_mode) LCHK(af_launch_fwd_multi_bf(&m, train ? 1 : 0, h->stream));
   else             LCHK(af_launch_fwd_multi(&m, train ? 1 : 0, h->stream));
@@ -520,6 +523,7 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
     fl += part_rows(p.a.tile0, p.a.NT, p.rows_total) * h->flop_dx[p.net];
   }
   if (m.n == 0) return 0;
+  if (h->step_stamp && (cls == T_BWD_1 || cls == T_BWD_2)) m.wg_stamp = h->step_stamp + (size_t)(cls == T_BWD_1 ? 2 : 3) * AF_STAMP_WG * 4;
   Timer t(h, cls, fl);
   m.nprod = h->mlp_mode == 2 ? 3 : 6;
   if (h->mlp_mode) LCHK(af_launch_bwd_multi_bf(&m, h->stream));
@@ -545,7 +549,7 @@ void plan_mapping_split(int ncu, int NT_map, int NT_atlas, int dep_rows, int& T1
 
 // dW of every layer of the schedule's nets + split-K reduction / Adam / weight-view re-emission + loss fold
 int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, float* loss_out, int loss_nblk, double dw_flops, bool check_counts = true) {
-  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock}; LCHK(af_launch_dw(&d, sc.nwg, h->dw_mode, h->stream)); }
+  { Timer t(h, T_DW, dw_flops); DwArgs d{sc.d_jobs, sc.d_segs, h->partial, h->dw_clock, h->step_stamp ? h->step_stamp + (size_t)4 * AF_STAMP_WG * 4 : nullptr}; LCHK(af_launch_dw(&d, sc.nwg, h->dw_mode, h->stream)); }
   {
     Timer t(h, T_ADAM);
     AdamArgs a{};
@@ -839,7 +843,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   // their shipped slot layout (`peg` above: five 3-D / ten 2-D frequencies) and padded K rows; k_adam, load_state_dict and the
   // repack of a mode switch only ever write the slots af_img_index() gives a real parameter, so the zeros written here are what
   // carries positional_encoding_num_* below the shipped count and the K padding.  Guard: tests/test_gpu_arch.py trains such
-  // configurations for several Adam steps against the oracle (a slot that picked up a value would show in the second step's losses).
+  // configurations for several Adam steps against the CPU restatement (a slot that picked up a value would show in the second step's losses).
   CCHK(hipMemset(h->img_f, 0, fc * 4)); CCHK(hipMemset(h->img_b, 0, bc * 4)); CCHK(hipMemset(h->bias_img, 0, biasc * 4));
   // batch buffers
   h->N = cfg->samples_batch;
@@ -886,7 +890,7 @@ void af_destroy(af_handle* h) {
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
   (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table); (void)hipFree(h->img_sf); (void)hipFree(h->img_sb);
   (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts); (void)hipFree(h->nan_flag); (void)hipFree(h->flow_rank); (void)hipFree(h->scan); (void)hipFree(h->live); (void)hipFree(h->nvalid);
-  (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
+  (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->step_stamp); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
   (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1217,6 +1221,20 @@ int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
   if (out && h->dw_clock) HCHK(hipMemcpy(out, h->dw_clock, (size_t)std::min(cap_wg, h->ncu) * 16, hipMemcpyDeviceToHost));
   if (!enable && h->dw_clock) { (void)hipFree(h->dw_clock); h->dw_clock = nullptr; }
   return h->ncu;
+}
+
+int af_debug_step_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
+  if (!h) return AF_EINVAL;
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  const size_t n = (size_t)5 * AF_STAMP_WG * 4;
+  if (enable && !h->step_stamp) { HCHK(dalloc(&h->step_stamp, n)); }
+  if (out && h->step_stamp) {
+    const int w = std::min(cap_wg, AF_STAMP_WG);
+    for (int l = 0; l < 5; ++l) HCHK(hipMemcpy(out + (size_t)l * w * 4, h->step_stamp + (size_t)l * AF_STAMP_WG * 4, (size_t)w * 32, hipMemcpyDeviceToHost));
+  }
+  if (h->step_stamp) HCHK(hipMemset(h->step_stamp, 0, n * 8));      // a launch smaller than the last one leaves zeros, not old stamps
+  if (!enable && h->step_stamp) { (void)hipFree(h->step_stamp); h->step_stamp = nullptr; }
+  return AF_STAMP_WG;
 }
 
 int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg) {

@@ -86,7 +86,9 @@ def check_counted_publish(name, ins, keep=16):
     """(b) the publish's counted vmcnt: exactly `keep` tile stores, and nothing else on the vector-memory counter, behind the last DMA piece."""
     n = 0
     for i, s in enumerate(ins):
-        if s.startswith("s_waitcnt") and "vmcnt(%d)" % keep in s:
+        # the publish is the asm `s_waitcnt vmcnt(KEEP) lgkmcnt(0)` directly in front of its s_barrier (hipcc's own counted waits for
+        # ordinary loads - e.g. the dPE block's vmcnt(16) - are neither)
+        if s.startswith("s_waitcnt") and "vmcnt(%d)" % keep in s and "lgkmcnt(0)" in s and i + 1 < len(ins) and ins[i + 1] == "s_barrier":
             stores = other = 0
             j = i - 1
             while j >= 0 and not ins[j].startswith("global_load_lds"):

@@ -133,6 +133,11 @@ int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[
 /* Balance diagnostics of k_dw: enable != 0 makes every later k_dw launch record s_memrealtime (100 MHz) at the start and
  * end of each workgroup; out (nullable) receives [min(cap_wg, #CUs)][2] values of the most recent launch.  Returns #CUs. */
 int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
+/* The clock each hot kernel runs at INSIDE the training step: enable != 0 makes the five hot launches of every later step (forward 1, 2,
+ * backward 1, 2 of the bf16 chains, k_dw) record per workgroup {s_memrealtime, s_memtime} at its start and at its end; out (nullable)
+ * receives [5][min(cap_wg, 4096)][4] uint64 of the most recent step (zeros for workgroups a launch did not have) and the buffer is
+ * cleared.  Ticks over the 100 MHz span = the shader clock under that launch's load (tools/step_clock.py).  Returns 4096. */
+int af_debug_step_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
 /* The static split-K schedule of k_dw: which = 0 (9 row segments), 1 (7), 2 / 3 (pre-train of mapping1 / mapping2).
  * out (nullable) [min(cap_wg, #workgroups)][16][4] int32 = {job shape 0..4 (8x8, 8x2, 8x1, 1x8, 1x2; -1 ends a list), first row tile,
  * one past the last, job index}.  Returns the number of workgroups.  Used by tools/dw_fit.py to fit the schedule's cost model. */

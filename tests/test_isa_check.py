@@ -34,14 +34,15 @@ def test_fragment_read_without_wait_is_caught():
 def test_counted_publish_is_checked():
     m = _mod()
     stores = ["buffer_store_dword v%d, v1, s[4:7], 0 offen" % i for i in range(16)]
-    ok = ["global_load_lds_dwordx4 v[2:3], off"] + stores[:5] + ["v_mfma_f32_32x32x16_bf16 a[0:15], a[16:19], v[8:11], a[0:15]"] + stores[5:] + ["s_waitcnt vmcnt(16) lgkmcnt(0)"]
+    ok = ["global_load_lds_dwordx4 v[2:3], off"] + stores[:5] + ["v_mfma_f32_32x32x16_bf16 a[0:15], a[16:19], v[8:11], a[0:15]"] + stores[5:] + ["s_waitcnt vmcnt(16) lgkmcnt(0)", "s_barrier"]
     assert m.check_counted_publish("k", ok) == 1
+    assert m.check_counted_publish("k", ok[:-2] + ["s_waitcnt vmcnt(16)", "v_add_f32_e32 v1, v2, v3"]) == 0      # hipcc's own counted wait for ordinary loads: not a publish
     with pytest.raises(RuntimeError, match="15 tile stores"):          # a store merged away / moved in front of the piece
         m.check_counted_publish("k", ok[:3] + ok[4:])
     with pytest.raises(RuntimeError, match="1 other"):                 # any other vector-memory instruction breaks the count
-        m.check_counted_publish("k", ok[:-1] + ["global_load_dword v9, v[2:3], off", ok[-1]])
+        m.check_counted_publish("k", ok[:-2] + ["global_load_dword v9, v[2:3], off"] + ok[-2:])
     with pytest.raises(RuntimeError):                                  # two stores merged into one wide store
-        m.check_counted_publish("k", ok[:1] + ["buffer_store_dwordx2 v[0:1], v1, s[4:7], 0 offen"] + stores[2:] + [ok[-1]])
+        m.check_counted_publish("k", ok[:1] + ["buffer_store_dwordx2 v[0:1], v1, s[4:7], 0 offen"] + stores[2:] + ok[-2:])
 
 
 def _slot_loop(m_per_gap=4, clump=False):

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   for (int w = 0; w < nwg; ++w) segs[(size_t)w * DW_MAXSEG] = DwSeg{0, w * per, (w + 1) * per, w};
   DwJob* dj; DwSeg* ds; CK(hipMalloc(&dj, sizeof j)); CK(hipMalloc(&ds, segs.size() * sizeof(DwSeg)));
   CK(hipMemcpy(dj, &j, sizeof j, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, segs.data(), segs.size() * sizeof(DwSeg), hipMemcpyHostToDevice));
-  DwArgs a{dj, ds, partial, nullptr};
+  DwArgs a{dj, ds, partial, nullptr, nullptr};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int mode = 0; mode < 3; ++mode) {
     for (int r = 0; r < 2; ++r) af_launch_dw(&a, nwg, mode, 0);
