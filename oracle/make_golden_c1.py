@@ -72,7 +72,31 @@ def shipped_config():
     return dict(mod.REFERENCE_CONFIG)
 
 
-def run_seed(seed, c, double=False, flow="constant"):
+def _grad64_step(models32, twins64, video64, i, jif, c, opt):
+    """--grad64: the gradient of iteration i from an fp64 twin of the CURRENT fp32 weights (forward and backward in fp64 on the same batch),
+    cast to fp32 and handed to the fp32 torch.optim.Adam of the fp32 weights.  Everything the run keeps between iterations (weights, Adam
+    moments, draws) is what the fp32 reference run keeps; only the round-off of torch's fp32 forward / backward inside ONE iteration is gone.
+    If the reference's fp32 gradient noise is what costs it ~0.1 dB against the HIP path, this arm must land where the
+    HIP path lands."""
+    for m32, m64 in zip(models32, twins64):
+        with torch.no_grad():
+            for p32, p64 in zip(m32.parameters(), m64.parameters()):
+                p64.copy_(p32.double()); p64.grad = None
+    torch.set_default_dtype(torch.float64)
+    try:
+        loss, terms = ref_iteration(i, jif, video64, twins64[0], twins64[1], c)
+        loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    opt.zero_grad()
+    for m32, m64 in zip(models32, twins64):
+        for p32, p64 in zip(m32.parameters(), m64.parameters()):
+            p32.grad = p64.grad.float()
+    opt.step()
+    return terms
+
+
+def run_seed(seed, c, double=False, flow="constant", grad64=False):
     video = O.synthetic_video(RESX, RESY, NF, seed=seed, flow=flow)
     torch.manual_seed(seed)
     # stage1_neural_atlas.py:112-128 (mapping first, then atlas)
@@ -85,6 +109,13 @@ def run_seed(seed, c, double=False, flow="constant"):
             if torch.is_tensor(v) and v.dtype == torch.float32:
                 setattr(video, k, v.double())
     opt = torch.optim.Adam([{"params": list(rm.parameters())}, {"params": list(ra.parameters())}], lr=0.0001)
+    if grad64:
+        import copy
+        twins = [copy.deepcopy(rm).double(), copy.deepcopy(ra).double()]
+        video64 = copy.copy(video)
+        for k, v in list(vars(video).items()):
+            if torch.is_tensor(v) and v.dtype == torch.float32:
+                setattr(video64, k, v.double())
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         pre_train_mapping(rm, NF, c["uv_mapping_scale"], resx=RESX, resy=RESY, larger_dim=video.larger_dim, device="cpu",
@@ -97,8 +128,11 @@ def run_seed(seed, c, double=False, flow="constant"):
     t0 = time.time()
     for i in range(ITERS):
         inds = torch.randint(jif_all.shape[1], (np.int64(N * 1.0), 1))
-        loss, terms = ref_iteration(i, jif_all[:, inds], video, rm, ra, c)
-        opt.zero_grad(); loss.backward(); opt.step()
+        if grad64:
+            terms = _grad64_step((rm, ra), twins, video64, i, jif_all[:, inds], c, opt)
+        else:
+            loss, terms = ref_iteration(i, jif_all[:, inds], video, rm, ra, c)
+            opt.zero_grad(); loss.backward(); opt.step()
         if i % LOG_EVERY == 0:
             curve.append(terms)
             print("seed %d iter %4d  total %.4f  rgb %.5f  (%.0f s)" % (seed, i, terms[5], terms[0], time.time() - t0), flush=True)
@@ -116,6 +150,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c1_reference.npz"))
     ap.add_argument("--double", action="store_true", help="run the schedule in fp64 from the fp32 initial weights (diagnostic: where exact arithmetic lands)")
     ap.add_argument("--merge", nargs="+", default=None, help="stack per-seed files written by earlier invocations into --out (thread counts and flow kinds are kept per seed)")
+    ap.add_argument("--grad64", action="store_true", help="fp32 weights, Adam state and draws; the gradient of every loop iteration from an fp64 twin (diagnostic: is torch-fp32's gradient round-off what separates the reference from the HIP path?)")
     ap.add_argument("--flow", default="constant", choices=["constant", "field"], help="round 4: 'field' = oracle.atlas_oracle.synthetic_video(flow='field'), a per-pixel, per-frame flow field with holed masks")
     args = ap.parse_args()
     if args.merge:
@@ -136,7 +171,7 @@ def main():
     if args.threads > 0:
         torch.set_num_threads(args.threads)
     c = shipped_config()
-    res = [run_seed(s, c, args.double, args.flow) for s in args.seeds]
+    res = [run_seed(s, c, args.double, args.flow, args.grad64) for s in args.seeds]
     np.savez_compressed(
         args.out, seeds=np.array(args.seeds), resx=RESX, resy=RESY, nframes=NF, iters=ITERS, pretrain_iters=PRETRAIN_ITERS, log_every=LOG_EVERY,
         psnr_pre=np.array([r["psnr_pre"] for r in res]), psnr=np.array([r["psnr"] for r in res]),

@@ -28,8 +28,9 @@ def _run(seed, g, injected=True):
     from oracle import atlas_oracle as O
     resx, resy, F = int(g["resx"]), int(g["resy"]), int(g["nframes"])
     iters, pre_iters = int(g["iters"]), int(g["pretrain_iters"])
-    v = O.synthetic_seg_video(resx, resy, F, seed=seed)
     k = [i for i, s in enumerate(g["seeds"]) if int(s) == seed][0]
+    flow = str(g["flow_kind"][k]) if "flow_kind" in g else "constant"      # round 4: odd further seeds run on the per-pixel flow field
+    v = O.synthetic_seg_video(resx, resy, F, seed=seed, flow=flow)
     assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"][k])) < 1e-6
     assert abs(float(v.mask_frames.double().sum()) - float(g["mask_checksum"][k])) < 1e-6
     af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F, two_layer=True))

@@ -194,17 +194,21 @@ def test_complete_schedule_fixtures_describe_the_videos_the_gpu_tests_rebuild():
     for fn in ("c1_reference.npz", "c1_reference_more.npz"):
         g = dict(np.load(os.path.join(gd, fn)))
         for k, s in enumerate(g["seeds"]):
-            v = O.synthetic_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=int(s))
+            flow = str(g["flow_kind"][k]) if "flow_kind" in g else "constant"
+            v = O.synthetic_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=int(s), flow=flow)
             assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"][k])) < 1e-6, (fn, int(s))
         assert (g["psnr"] > g["psnr_pre"] + 5.0).all() and (g["curves"][:, -1, 5] < 0.2 * g["curves"][:, 0, 5]).all()
     g = dict(np.load(os.path.join(gd, "c1_seg_reference.npz")))
     seeds = sorted({int(s) for s in g["seeds"]})
     assert len(seeds) >= 3
+    pairs = 0
     for s in seeds:
         runs = [i for i in range(len(g["seeds"])) if int(g["seeds"][i]) == s and int(g["double"][i]) == 0]
-        assert len({int(g["threads"][i]) for i in runs}) >= 2, s          # the reference against itself: the tolerance construction needs pairs
-        v = O.synthetic_seg_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=s)
+        pairs += len({int(g["threads"][i]) for i in runs}) >= 2
+        flow = str(g["flow_kind"][runs[0]]) if "flow_kind" in g else "constant"
+        v = O.synthetic_seg_video(int(g["resx"]), int(g["resy"]), int(g["nframes"]), seed=s, flow=flow)
         for i in runs:
             assert abs(float(v.video_frames.double().sum()) - float(g["video_checksum"][i])) < 1e-6
             assert abs(float(v.mask_frames.double().sum()) - float(g["mask_checksum"][i])) < 1e-6
             assert g["psnr"][i] > g["psnr_pre"][i] + 3.0 and g["curves"][i][-1, 11] < 0.2 * g["curves"][i][0, 11]
+    assert pairs >= 3          # the reference against itself (two thread counts) on at least three seeds: the tolerance construction needs pairs
