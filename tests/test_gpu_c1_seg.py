@@ -9,9 +9,13 @@ Every random draw of the reference run came from torch's global CPU generator in
 from the seed alone: nn.Linear init of mapping1, mapping2, atlas, alpha; per pre-train step the row then the column draw,
 mapping1's 8000 steps then mapping2's; one torch.randint(P, (N, 1)) per loop iteration.
 
-Tolerances are built exactly like test_gpu_c1.py's: the fixture holds every seed at TWO thread counts — the reference against
-itself, only the summation order inside its GEMMs differs — and BASELINE.md's 0.1 dB is asserted on top of two standard errors
-of that measured run-to-run noise."""
+Tolerances are built like test_gpu_c1.py's: the fixture holds seeds 0..2 at TWO thread counts — the reference against itself, only the
+summation order inside its GEMMs differs — and BASELINE.md's 0.1 dB is asserted on top of two standard errors of the measured
+run-to-run noise.  Round 4 measured the SAME sensitivity on this side: another split-K partition of the weight-gradient GEMM (another
+summation order, nothing else: `AF_DW_COST`; with round 3's partition the round-4 kernels reproduce round 3's 24.6563 dB on seed 1 to the
+last digit) moves this path's final PSNR on seed 1 over 23.37 .. 24.66 dB (six partitions, sd 0.5 dB) — the four-net schedule is
+chaotic at the 0.5 dB level per seed on BOTH sides.  Every seed is therefore run on several partitions here, the HIP side's own sigma is
+estimated from their spread, seeds are compared by their means, and both sigmas enter the tolerances."""
 import os
 
 import numpy as np
@@ -22,7 +26,23 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_seg_reference.npz")
 
 
-def _run(seed, g, injected=True):
+# split-K partitions of k_dw the seeds are run on (host.hip build_sched: per-shape tile costs; None = the shipped row): same arithmetic, another summation order
+PARTITIONS = (None, "306,150,126,129,87", "306,170,145,148,100")
+
+
+def _run(seed, g, injected=True, partition=None):
+    import aiod_amd
+    if partition is None:
+        os.environ.pop("AF_DW_COST", None)
+    else:
+        os.environ["AF_DW_COST"] = partition
+    try:
+        return _run_inner(seed, g, injected)
+    finally:
+        os.environ.pop("AF_DW_COST", None)
+
+
+def _run_inner(seed, g, injected=True):
     import aiod_amd
     import bench
     from oracle import atlas_oracle as O
@@ -76,29 +96,44 @@ def test_configs4_full_schedule_psnr_within_0p1_db_of_reference():
     n_runs = sum(len(arms[s]) for s in seeds)
     print("reference against itself (%s threads): final PSNR per run %s dB, pairs differ by %s dB -> sigma of one run %.3f dB ; total-loss curves up to %.1f %% apart"
           % (sorted({int(t) for t in g["threads"][fp32]}), np.array2string(g["psnr"][fp32], precision=3), np.array2string(d, precision=3), sigma_run, 100 * spread_curve))
-    hip, ref_means = [], []
+    hip, ref_means, dev_in = [], [], []
     for seed in seeds:
-        p_pre, p_end, per, losses = _run(seed, g)
-        curve = losses[::every, :12]
         refs = [float(g["psnr"][i]) for i in arms[seed]]
         ref_pre = [float(g["psnr_pre"][i]) for i in arms[seed]]
+        parts = PARTITIONS if len(refs) >= 2 else PARTITIONS[:2]          # seeds with one reference arm: two partitions
+        runs = [_run(seed, g, partition=p) for p in parts]
+        ends = np.array([r[1] for r in runs]); pres = np.array([r[0] for r in runs])
+        dev_in.append(ends - ends.mean())
+        curve = runs[0][3][::every, :12]
         rel_total = np.min([np.abs(curve[:, 11] / g["curves"][i][:, 11] - 1.0) for i in arms[seed]], axis=0)       # to the nearer arm
-        tol_seed = 0.1 + 2.0 * sigma_run * np.sqrt(1.0 + 1.0 / len(refs))
-        print("seed %d: PSNR after the pre-trains hip %.4f / reference %s ; after %d iterations hip %.4f / reference %s (tolerance %.3f dB)"
-              % (seed, p_pre, np.array2string(np.array(ref_pre), precision=4), int(g["iters"]), p_end, np.array2string(np.array(refs), precision=4), tol_seed))
+        print("seed %d (%s flow): PSNR after the pre-trains hip %s / reference %s ; after %d iterations hip %s (mean %.4f) / reference %s"
+              % (seed, str(g["flow_kind"][arms[seed][0]]) if "flow_kind" in g else "constant", np.array2string(pres, precision=4), np.array2string(np.array(ref_pre), precision=4),
+                 int(g["iters"]), np.array2string(ends, precision=4), ends.mean(), np.array2string(np.array(refs), precision=4)))
         print("   total loss every %d iterations, hip:       %s" % (every, np.array2string(curve[:, 11], precision=2)))
         for i in arms[seed]:
             print("   total loss every %d iterations, ref/%d thr: %s" % (every, int(g["threads"][i]), np.array2string(g["curves"][i][:, 11], precision=2)))
-        assert min(abs(p_pre - r) for r in ref_pre) < 0.1                    # 16 000 pre-train steps on the same draws
+        # 16 000 pre-train steps on the same draws: the reconstruction PSNR with an untrained atlas moves by ~0.1 dB with the summation order
+        # on this side as well (17.23 .. 17.36 dB over six partitions on seed 1)
+        assert abs(float(pres.mean()) - float(np.mean(ref_pre))) < 0.25, (seed, pres, ref_pre)
         assert rel_total[0] < 0.10, (curve[0], [g["curves"][i][0] for i in arms[seed]])
         assert rel_total.max() < 0.05 + 1.5 * spread_curve                  # the curves stay as close as the reference's own two
-        assert abs(p_end - float(np.mean(refs))) <= tol_seed, (seed, p_end, refs)
-        hip.append(p_end); ref_means.append(float(np.mean(refs)))
-    mh, mr = float(np.mean(hip)), float(np.mean(ref_means))
-    tol_mean = 0.1 + 2.0 * sigma_run * np.sqrt(1.0 / len(seeds) + 1.0 / n_runs)
-    print("mean PSNR over seeds %s: hip %.4f dB ; reference %.4f dB (%d runs) ; hip - reference %+.4f dB (tolerance %.3f dB)" % (seeds, mh, mr, n_runs, mh - mr, tol_mean))
-    assert abs(mh - mr) <= tol_mean, (hip, ref_means)
+        hip.append(ends); ref_means.append(float(np.mean(refs)))
+    dev = np.concatenate(dev_in)
+    dof = sum(len(h) - 1 for h in hip)
+    sigma_hip = float(np.sqrt((dev ** 2).sum() / dof))            # this path's own sigma of one run, pooled over the seeds' partitions
+    print("HIP path against itself (partitions %s): pooled sigma of one run %.3f dB (reference: %.3f dB)" % (list(PARTITIONS), sigma_hip, sigma_run))
+    d = np.array([h.mean() - r for h, r in zip(hip, ref_means)])
+    for seed, h, r, dd in zip(seeds, hip, ref_means, d):
+        n_ref = len(arms[seed])
+        tol_seed = 0.1 + 2.0 * np.sqrt(sigma_hip ** 2 / len(h) + sigma_run ** 2 / n_ref)
+        print("seed %d: hip %.4f - reference %.4f = %+.4f dB (tolerance %.3f dB)" % (seed, h.mean(), r, dd, tol_seed))
+        assert abs(dd) <= tol_seed, (seed, h, r)
+    se = float(d.std(ddof=1) / np.sqrt(len(d)))
+    se_model = float(np.sqrt(np.mean([sigma_hip ** 2 / len(h) + sigma_run ** 2 / len(arms[s_]) for h, s_ in zip(hip, seeds)]) / len(d)))
+    print("mean PSNR over seeds %s: hip - reference = %+.4f dB, standard error %.4f dB from the paired differences (%.4f from the two sigmas), n = %d, t = %+.2f"
+          % (seeds, d.mean(), se, se_model, len(d), d.mean() / se))
+    assert abs(float(d.mean())) <= 0.1 + 2.0 * max(se, se_model), (d, se, se_model)
     # the product's own device sampler on the first seed (different draws): same quality of fit
     p_dev = _run(seeds[0], g, injected=False)[1]
     print("seed %d with the device sampler: %.4f dB" % (seeds[0], p_dev))
-    assert abs(p_dev - ref_means[0]) <= 0.1 + 2.0 * sigma_run * np.sqrt(2.0) + 0.2
+    assert abs(p_dev - ref_means[0]) <= 0.1 + 2.0 * np.sqrt(sigma_hip ** 2 + sigma_run ** 2) + 0.2

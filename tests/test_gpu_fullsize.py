@@ -87,6 +87,25 @@ def test_full_size_iteration_matches_oracle(full):
         assert (int(hip[6]), int(hip[7])) == (nf, nb)
 
 
+class _F64:
+    """torch default dtype float64 inside the block (the oracle's coordinate normalisation follows the default dtype)."""
+    def __enter__(self):
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(torch.float32)
+
+
+def _twin64(models):
+    """fp64 copies of oracle models: the yardstick for how much fp32 round-off ANY fp32 implementation (torch's included) carries on a state."""
+    import copy
+    out = [copy.deepcopy(m).double() for m in models]
+    for m in out:
+        if getattr(m, "use_positional", False):
+            m.b = m.b.double()
+    return out
+
+
 def _copy_params_to_oracle(af, nets, models):
     for net, m in zip(nets, models):
         flat, off = af.get_params_flat(net), 0
@@ -114,6 +133,11 @@ def test_full_size_trajectory_matches_oracle(full):
     m, a = O.build_single_atlas_models(cfg, seed=0)
     _copy_params_to_oracle(af, nets, (m, a))
     tr = O.SingleAtlasTrainer(cfg, v, mapping=m, atlas=a)
+    # fp64 twin of the oracle from the same state (see test_full_size_seg_trajectory_matches_oracle): the 1e-3 is widened by torch-fp32's own
+    # measured distance from it on that term and iteration, by nothing else, and the HIP trajectory may be no further from fp64 than that
+    m64, a64 = _twin64((m, a))
+    v64 = O.Video(frames.double(), flows[..., None].double(), flows_rev[..., None].double(), mask[..., None], mask_rev[..., None])
+    tr64 = O.SingleAtlasTrainer(cfg, v64, mapping=m64, atlas=a64)
     g = torch.Generator().manual_seed(17)
     K, first = 10, 4996
     inds = torch.randint(v.F * v.resx * v.resy, (K, cfg["samples_batch"]), generator=g)
@@ -121,11 +145,17 @@ def test_full_size_trajectory_matches_oracle(full):
     names = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
     for k in range(K):
         t = tr.step(first + k, inds[k])
-        want = np.array([t[n] for n in names])
-        rel = np.abs(hip[k, :6] - want) / np.maximum(np.abs(want), 1e-12)
-        rel[3] = 0.0 if want[3] == 0 and hip[k, 3] == 0 else rel[3]
-        print(first + k, "rel", rel, "rigidity", want[2])
-        assert rel.max() < 1e-3, (first + k, hip[k], want)
+        with _F64():
+            t64 = tr64.step(first + k, inds[k])
+        want, f64 = np.array([t[n] for n in names]), np.array([t64[n] for n in names])
+        on = np.abs(want) > 0
+        rel, e_ref, e_hip = np.zeros(6), np.zeros(6), np.zeros(6)
+        rel[on] = np.abs(hip[k, :6][on] - want[on]) / np.abs(want[on])
+        e_ref[on] = np.abs(want[on] - f64[on]) / np.abs(f64[on]); e_hip[on] = np.abs(hip[k, :6][on] - f64[on]) / np.abs(f64[on])
+        assert np.all(hip[k, :6][~on] == 0)
+        print(first + k, "max rel: hip-vs-torch-fp32 %.3g (term %d) | vs the fp64 twin: hip %.3g  torch-fp32 %.3g" % (rel.max(), int(rel.argmax()), e_hip.max(), e_ref.max()), "rigidity", want[2])
+        assert np.all(rel <= 1e-3 + 1.05 * e_ref), (first + k, hip[k], want, rel, e_ref)
+        assert np.all(e_hip <= 1e-3 + 1.05 * e_ref), (first + k, hip[k], f64, e_hip, e_ref)
         assert (want[3] > 0) == (first + k <= 5000)
     assert 2.5 < hip[0, 2] < 6.0                             # near-rigid after the pre-train
     for net, mdl in zip(nets, (m, a)):
@@ -161,6 +191,7 @@ def test_full_size_seg_iteration_matches_oracle():
     models = O.build_seg_models(cfg, seed=0)
     _copy_params_to_oracle(af, nets, models)
     tr = O.SegAtlasTrainer(cfg, v, models=models)
+    v64 = O.SegVideo(frames.double(), flows[..., None].double(), flows_rev[..., None].double(), mask[..., None], mask_rev[..., None], fg.cpu().double())
     g = torch.Generator().manual_seed(23)
     N = cfg["samples_batch"]
     rows, flops = af.step_work(0)
@@ -173,17 +204,25 @@ def test_full_size_seg_iteration_matches_oracle():
             z = np.zeros(af.param_count(net), np.float32)
             af.set_adam_state(net, z, z, 0)
         ref = tr.loss_and_grads(it, inds)
+        m64 = _twin64(models)
+        tr64 = O.SegAtlasTrainer(cfg, v64, models=m64)
+        with _F64():
+            tr64.loss_and_grads(it, inds)
         hip = af.train_steps(it, 1, inds.numpy())[0]
         want = np.array([ref[k] for k in O.SEG_TERMS])
         rel = np.abs(hip[:12] - want) / np.maximum(np.abs(want), 1e-12)
         print(it, "hip", hip[:12], "oracle", want, "rel", rel)
         assert np.allclose(hip[:12], want, rtol=1e-3, atol=1e-7), (it, hip, want)
         assert 2.5 < hip[2] < 6.0 and 2.5 < hip[3] < 6.0
-        for net, mdl in zip(nets, models):
-            gh, go = af.last_grads(net), O.flat_grads(mdl)
-            e = np.linalg.norm(gh - go) / np.linalg.norm(go)
-            print(it, "net", net, "gradient rel (L2) hip vs oracle %.3g  norm %.4g" % (e, np.linalg.norm(go)))
-            assert e < 1e-3, (it, net, e)
+        for net, mdl, mdl64 in zip(nets, models, m64):
+            # against torch-fp32 within 1e-3 + torch-fp32's OWN distance from the fp64 twin on this state (the atlas net's gradient through
+            # 2^9 pi Fourier features carries 1e-3 .. 3e-3 of round-off in torch-fp32, tests/test_gpu_seg.py), and never further from fp64 than it
+            gh, go, g64 = af.last_grads(net), O.flat_grads(mdl), O.flat_grads(mdl64)
+            n64 = np.linalg.norm(g64)
+            e, e_hip, e_o32 = np.linalg.norm(gh - go) / np.linalg.norm(go), np.linalg.norm(gh - g64) / n64, np.linalg.norm(go - g64) / n64
+            print(it, "net", net, "gradient rel (L2) hip vs oracle %.3g  norm %.4g | vs the fp64 twin: hip %.3g  torch-fp32 %.3g" % (e, np.linalg.norm(go), e_hip, e_o32))
+            assert e < 1e-3 + 1.05 * e_o32, (it, net, e, e_o32)
+            assert e_hip < max(3 * e_o32, 1e-5), (it, net, e_hip, e_o32)
         jif = tr.jif_all[:, inds]
         nf = int((v.optical_flows_mask[jif[1], jif[0], jif[2], 0] != 0).sum()); nb = int((v.optical_flows_reverse_mask[jif[1], jif[0], jif[2], 0] != 0).sum())
         assert (int(hip[12]), int(hip[13])) == (nf, nb)
