@@ -107,11 +107,12 @@ def test_field_video_has_a_per_pixel_flow_that_moves_its_texture():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference not mounted (GPU box)")
-def test_restatement_against_live_reference_modules():
+@pytest.mark.parametrize("flow", ["constant", "field"])
+def test_restatement_against_live_reference_modules(flow):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", AF_GOLDEN_CHECK_ONLY="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py")], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), flow], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
 
 
