@@ -1227,7 +1227,7 @@ int af_debug_step_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
   if (!h) return AF_EINVAL;
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
   const size_t n = (size_t)5 * AF_STAMP_WG * 4;
-  if (enable && !h->step_stamp) { HCHK(dalloc(&h->step_stamp, n)); }
+  if (enable && !h->step_stamp) { HCHK(dalloc(&h->step_stamp, n)); HCHK(hipMemset(h->step_stamp, 0, n * 8)); }
   if (out && h->step_stamp) {
     const int w = std::min(cap_wg, AF_STAMP_WG);
     for (int l = 0; l < 5; ++l) HCHK(hipMemcpy(out + (size_t)l * w * 4, h->step_stamp + (size_t)l * AF_STAMP_WG * 4, (size_t)w * 32, hipMemcpyDeviceToHost));

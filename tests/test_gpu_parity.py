@@ -296,3 +296,26 @@ def test_more_error_paths(golden, small_video):
     l = h.train_steps(0, 1, None, seed=1)                                                                        # and the handle still trains
     assert np.isfinite(l).all()
     h.close()
+
+
+def test_step_clocks_stamp_every_hot_launch(af, golden):
+    """af_debug_step_clocks (include/atlasfit.h): with the stamps on, the five hot launches of a step record s_memrealtime / s_memtime per
+    workgroup at its start and end; ticks over the 100 MHz span is a shader clock (tools/step_clock.py reads it inside the bench loop)."""
+    import aiod_amd
+    m, a = _oracle_models(golden)
+    af.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict()); af.load_state_dict(aiod_amd.NET_ATLAS, a.state_dict())
+    first = af.step_clocks(True)
+    assert set(first) == set(af.STEP_CLOCK_LAUNCHES) and all(len(v) == 0 for v in first.values())      # nothing stamped yet: zeros, not garbage
+    af.train_steps(0, 3, None, seed=5, return_losses=False)
+    st = af.step_clocks(False)                                                                          # read and switch off
+    for name in ("fwd_2", "bwd_1", "dw"):                                                               # (a small batch has no whole round of mapping tiles: fwd_1 / bwd_2 may be empty)
+        c = st[name].astype(np.float64)
+        assert len(c) >= 1, name
+        assert (c[:, 2] >= c[:, 0]).all() and (c[:, 3] > c[:, 1]).all(), name
+        span_us = (c[:, 2] - c[:, 0]) / 100.0
+        busy = span_us > 2.0
+        if busy.any():
+            mhz = (c[busy, 3] - c[busy, 1]) / span_us[busy]
+            assert (mhz > 300).all() and (mhz < 3000).all(), (name, mhz)
+    af.train_steps(0, 1, None, seed=5, return_losses=False)
+    assert all(len(v) == 0 for v in af.step_clocks(False).values())                                     # off: no stamps
