@@ -460,8 +460,11 @@ class AtlasFit:
         self._chk(self.lib.af_get_last_grads(self.h, net, _ptr(g), g.size))
         return g
 
-    def set_timing(self, mask=0xFFFF):
-        self._chk(self.lib.af_set_timing(self.h, int(mask) if not isinstance(mask, bool) else (0xFFFF if mask else 0)))
+    def set_timing(self, mask=0xFFFF, every=1):
+        """HIP events around the launch classes in `mask`; `every` = P: only every P-th step of a train_steps call is timed (an event
+        costs ~5 us in-stream)."""
+        m = int(mask) if not isinstance(mask, bool) else (0xFFFF if mask else 0)
+        self._chk(self.lib.af_set_timing(self.h, (m & 0xFFFF) | ((max(1, int(every)) & 0xFF) << 16)))
 
     def timing(self, reset=True):
         """{launch class: (milliseconds, launches, algorithmic FLOPs)} accumulated since the last reset."""

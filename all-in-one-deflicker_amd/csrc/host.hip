@@ -114,7 +114,7 @@ struct af_handle {
   // render
   int render_rows_cap = 0; float *r_coords = nullptr, *r_uv = nullptr, *r_uv2 = nullptr, *r_al = nullptr, *r_t = nullptr, *r_rgb = nullptr; double* r_sse = nullptr;
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
-  bool debug = false; unsigned timing = 0;
+  bool debug = false; unsigned timing = 0, timing_every = 1; bool timing_live = true;   // timing_every: af_set_timing's sample period; timing_live: this step of af_train_steps is a sampled one
   double flop_fwd[AF_MAX_NETS] = {0}, flop_dx[AF_MAX_NETS] = {0};     // algorithmic FLOPs per MLP row of each net as built (forward == dW; dX chain), BASELINE.md 3
   int dw_mode = 1;                            // k_dw arithmetic (dw.hip): 1 = bf16x6 (fp32-faithful, the default), 2 = bf16x3 (hi + mid bf16 per operand, three products; opt-in), 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
@@ -460,7 +460,7 @@ struct Timer {
     if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); h->t_flops[cls] += flops; }
   }
   ~Timer() { if (on()) { (void)hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); } }
-  bool on() const { return (h->timing >> cls) & 1u; }
+  bool on() const { return h->timing_live && ((h->timing >> cls) & 1u); }
 };
 
 void drain_timers(af_handle* h) {
@@ -1034,7 +1034,13 @@ int af_set_mlp_mode(af_handle* h, int mode) {
   return AF_OK;
 }
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }
-int af_set_timing(af_handle* h, int class_mask) { if (!h) return AF_EINVAL; h->timing = (unsigned)class_mask & 0xFFFFu; return AF_OK; }
+int af_set_timing(af_handle* h, int class_mask) {
+  if (!h) return AF_EINVAL;
+  h->timing = (unsigned)class_mask & 0xFFFFu;
+  const unsigned every = ((unsigned)class_mask >> 16) & 0xFFu;      // an event costs ~5 us in-stream: a caller timing a region may sample every P-th step
+  h->timing_every = every ? every : 1;
+  return AF_OK;
+}
 int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset) {
   if (!h) return AF_EINVAL;
   (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); drain_timers(h);
@@ -1131,8 +1137,10 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
   for (int k = 0; k < n_iters && rc == 0; ++k) {
     const int64_t* di = d_inds ? d_inds + (size_t)k * N : nullptr;
     float* lo = h->loss_log + (size_t)k * AF_LOSS_W;
+    h->timing_live = (k % (int)h->timing_every) == 0;
     rc = h->seg ? enqueue_seg_step(h, first_iter + k, di, seed, lo) : enqueue_single_step(h, first_iter + k, di, seed, lo);
   }
+  h->timing_live = true;
   hipError_t e = hipStreamSynchronize(h->stream);
   drain_timers(h);
   if (d_inds) (void)hipFree(d_inds);

@@ -366,6 +366,9 @@ def hbm_model_bytes(kernel, rows4, launches_per_step):
     return (sum(per_row[n] * r[n] for n in r) + streams) / launches_per_step
 
 
+EVENT_EVERY = 4     # the timed region's HIP events sit in every 4th step (af_set_timing's sample period)
+
+
 def committed_traffic(kernel, model_bytes, tol=0.12):
     """The newest profiles/r*_traffic.json that holds `kernel`: (bytes per launch, source) when the measurement agrees
     with the layout model within `tol`, else (None, why)."""
@@ -467,7 +470,10 @@ def main():
     # the dominant KERNEL (by name, all of its launches in a step: k_mlp_fwd_multi = fwd_1 + fwd_2, ...), not the dominant launch
     dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["bwd_1"]
     dom_classes = by_name[dom]
-    af.set_timing(sum(1 << classes.index(c) for c in dom_classes))   # events only around the dominant kernel's launches
+    # events only around the dominant kernel's launches, and only in every EVENT_EVERY-th timed step: an event costs ~5 us in-stream
+    # (the all-launches pass below runs 0.06 ms per step slower than the timed region for its 12 further events), four of them in
+    # every step of a 1.1 ms step would take 1.8 % off `value` for the sake of measuring `roofline`
+    af.set_timing(sum(1 << classes.index(c) for c in dom_classes), every=EVENT_EVERY)
 
     # ---- optional extra videos on this GPU (own handle, stream, weights, table), warmed like the first
     extra = []
@@ -539,16 +545,20 @@ def main():
     rows_mean = tuple(sum(live_rows(r)[j] for r in rows_k) / K for j in range(4))
     dw_alg_bytes = hbm_model_bytes("k_dw", rows_mean, 1)           # algorithmic = every operand tile of every layer read once
 
-    def masked_of(kname, cls):
+    def masked_of(kname, cls, inv_rows=None):
+        inv_rows = inv if inv_rows is None else inv_rows
         if "dw" in cls:
-            return masked_dw_flops
-        return inv * (sum(FWD[n] for n in nets_inv) if kname.startswith("k_mlp_fwd") else sum(DX[n] for n in nets_inv)) if kname.startswith("k_mlp") else 0.0
+            return inv_rows * sum(FWD[n] for n in nets_inv)
+        return inv_rows * (sum(FWD[n] for n in nets_inv) if kname.startswith("k_mlp_fwd") else sum(DX[n] for n in nets_inv)) if kname.startswith("k_mlp") else 0.0
 
     # ---- roofline of the dominant kernel: algorithmic FLOPs / bytes per launch over the mean HIP-event duration of the TIMED region
+    sampled = list(range(0, K, EVENT_EVERY))                         # the timed steps whose launches carried events (af_set_timing's period)
+    inv_sampled = float((2 * N - nv[sampled].sum(axis=1)).sum())
     n_launch = max(sum(tk[c][1] for c in dom_classes), 1)
+    launches_per_step = n_launch / len(sampled)
     dom_ms = sum(tk[c][0] for c in dom_classes) / n_launch
     is_dw = "dw" in dom_classes
-    flops_launch = (sum(tk[c][2] for c in dom_classes) - masked_of(dom, dom_classes)) / n_launch
+    flops_launch = (sum(tk[c][2] for c in dom_classes) - masked_of(dom, dom_classes, inv_sampled)) / n_launch
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
     mfma_peak = (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS if DW_BF else FP32_MFMA_PEAK_TFLOPS) if is_dw else (BF16X6_PEAK_TFLOPS if MLP_BF else FP32_MFMA_PEAK_TFLOPS)
@@ -583,7 +593,7 @@ def main():
     # covers this kernel and agrees with the byte model of THIS run's rows (hbm_model_bytes) - a stale file yields null.
     traffic, traffic_src = None, None
     if (args.resx, args.resy, args.frames) == (768, 432, 80) and not extra:
-        traffic, traffic_src = committed_traffic(dom, hbm_model_bytes(dom, rows_mean, n_launch / K))
+        traffic, traffic_src = committed_traffic(dom, hbm_model_bytes(dom, rows_mean, launches_per_step))
 
     out = None
     if rank == 0:
@@ -607,7 +617,7 @@ def main():
             "pretrain_ms_per_step": pre_ms,
             "roofline": {**roof, "kernel": dom, "kernel_launch_classes": dom_classes, "achieved_tflops": achieved,
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                         "kernel_ms": dom_ms, "flops_per_launch": flops_launch, "launches_per_step": n_launch / K,
+                         "kernel_ms": dom_ms, "kernel_events": "HIP events on the handle's stream around this kernel's launches in every %d-th of the %d timed steps (%d launches)" % (EVENT_EVERY, K, n_launch), "flops_per_launch": flops_launch, "launches_per_step": launches_per_step,
                          "by_kernel": by_kernel,
                          "valid_flow_fraction": float(nv.sum() / (2.0 * N * K)),
                          "whole_step_tflops": V * total_flops / dt / 1e12, "whole_step_frac": V * total_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS},

@@ -166,8 +166,11 @@ int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);
  * launch class since the last reset: [0]=prep [1]=fwd_1 [2]=fwd_2 [3]=loss [4]=bwd_1 [5]=bwd_2 [6]=dw [7]=adam.
  * A step has two forward and two backward MLP launches: fwd_1 = the mapping batch's whole rounds (two_layer:
  * alpha + both mappings), fwd_2 = atlas + the remainder; bwd_1 = atlas + remainder, bwd_2 = the rest.
- * ms16[16], counts16[16], flops16[16] (any may be NULL). */
-int af_set_timing(af_handle* h, int class_mask);   /* bit i enables HIP-event timing of launch class i */
+ * ms16[16], counts16[16], flops16[16] (any may be NULL).
+ * Bits 16..23 of class_mask: sample period P (0 or 1 = every step) - only the launches of every P-th step of an af_train_steps call
+ * (its first step, its (P+1)-th, ...) carry events: a HIP event costs ~5 us in-stream, so timing two launches of every step of a
+ * 1.1 ms step slows it by ~1.8 %; counts16 / flops16 cover exactly the launches that were timed. */
+int af_set_timing(af_handle* h, int class_mask);   /* bit i (0..15) enables HIP-event timing of launch class i */
 int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16, int reset);
 /* Algorithmic work of ONE train step at the given iteration: MLP rows per net (indexed by af_net) and the
  * fwd+bwd FLOPs of the step. */

@@ -319,3 +319,30 @@ def test_step_clocks_stamp_every_hot_launch(af, golden):
             assert (mhz > 300).all() and (mhz < 3000).all(), (name, mhz)
     af.train_steps(0, 1, None, seed=5, return_losses=False)
     assert all(len(v) == 0 for v in af.step_clocks(False).values())                                     # off: no stamps
+
+
+def test_event_timing_sample_period(golden, small_video):
+    """af_set_timing's sample period (bits 16..23 of the mask; include/atlasfit.h): with period P only every P-th step of an
+    af_train_steps call carries HIP events, counts and FLOPs cover exactly those launches, and the results do not depend on it."""
+    import aiod_amd
+    m, a = _oracle_models(golden)
+
+    def run(every):
+        h = aiod_amd.AtlasFit(_cfg(golden, pretrain_batch=int(golden["pre_batch"])))          # a fresh handle: fresh Adam state
+        _upload(h, small_video)
+        h.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict()); h.load_state_dict(aiod_amd.NET_ATLAS, a.state_dict())
+        h.set_timing(0xFFFF, every=every)
+        losses = h.train_steps(0, 10, None, seed=5, return_losses=True)
+        t = h.timing(reset=True)
+        h.set_timing(0)
+        h.train_steps(10, 2, None, seed=5, return_losses=False)
+        off = h.timing(reset=True)["dw"][1]
+        h.close()
+        return losses, t, off
+    l1, t1, off1 = run(1)
+    l4, t4, off4 = run(4)
+    assert t1["dw"][1] == 10 and t1["adam"][1] == 10 and t1["fwd_2"][1] == 10
+    assert t4["dw"][1] == 3 and t4["adam"][1] == 3 and t4["fwd_2"][1] == 3            # steps 0, 4, 8 of the call
+    assert t4["dw"][0] > 0 and 0.2 * t1["dw"][2] < t4["dw"][2] < 0.4 * t1["dw"][2]    # FLOPs of the three timed launches only (the fixture's schedule switches regime inside the ten steps)
+    assert np.array_equal(l1, l4)                                                    # timing never changes results
+    assert off1 == 0 and off4 == 0                                                   # mask 0: no events
