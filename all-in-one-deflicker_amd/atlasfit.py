@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
     "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_debug_step_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
+    "af_debug_set_dw_cost",
 ]
 
 
@@ -175,6 +176,7 @@ def load_library(path=None):
         "af_debug_dw_schedule": (i32, [vp, i32, vp, i32]),
         "af_set_dw_mode": (i32, [vp, i32]),
         "af_set_mlp_mode": (i32, [vp, i32]),
+        "af_debug_set_dw_cost": (i32, [vp, vp, C.c_double]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -303,6 +305,23 @@ class AtlasFit:
             if n != built:
                 self.close()
                 raise AtlasFitError(-1, "net %d: config describes %d parameters, libatlasfit.so built %d" % (net, n, built))
+        self._apply_experiment_env()
+
+    def _apply_experiment_env(self):
+        """The A/B tools' environment switches, mapped onto the explicit calls (libatlasfit.so itself reads no environment):
+        AF_MLP_MODE / AF_MLP_FP32, AF_DW_MODE / AF_DW_FP32 (include/atlasfit.h: af_set_mlp_mode, af_set_dw_mode) and
+        AF_DW_COST="c8x8,c8x2,c8x1,c1x8,c1x2[,seg]" (af_debug_set_dw_cost; tools/dw_cost_sweep.sh)."""
+        env = os.environ
+        if env.get("AF_MLP_FP32") and int(env["AF_MLP_FP32"]):
+            self.set_mlp_mode(0)
+        elif env.get("AF_MLP_MODE"):
+            self.set_mlp_mode(int(env["AF_MLP_MODE"]))
+        if env.get("AF_DW_FP32") and int(env["AF_DW_FP32"]):
+            self.set_dw_mode(0)
+        elif env.get("AF_DW_MODE"):
+            self.set_dw_mode(int(env["AF_DW_MODE"]))
+        if env.get("AF_DW_COST"):
+            self.set_dw_cost(env["AF_DW_COST"])
 
     def close(self):
         if getattr(self, "h", None):
@@ -447,6 +466,22 @@ class AtlasFit:
         """k_dw arithmetic: 1 = bf16x6 (fp32-faithful; the default), 2 = bf16x3 (two bf16 per operand, three products: narrower than fp32, opt-in), 0 = fp32 MFMA."""
         self._chk(self.lib.af_set_dw_mode(self.h, int(mode)))
 
+    def set_dw_cost(self, row, seg_cost=0.0):
+        """Another split-K partition of k_dw (af_debug_set_dw_cost): row = five tile costs (8x8, 8x2, 8x1, 1x8, 1x2), a sequence or the
+        "a,b,c,d,e[,seg]" string of the sweep tools; None = the shipped row.  Same arithmetic, another summation order."""
+        if row is None:
+            self._chk(self.lib.af_debug_set_dw_cost(self.h, None, 0.0))
+            return
+        if isinstance(row, str):
+            vals = [float(x) for x in row.split(",")]
+            if len(vals) == 6:
+                seg_cost = vals[5]
+            row = vals[:5]
+        if len(row) != 5:
+            raise ValueError("set_dw_cost: five tile costs (8x8, 8x2, 8x1, 1x8, 1x2)")
+        arr = (C.c_double * 5)(*[float(x) for x in row])
+        self._chk(self.lib.af_debug_set_dw_cost(self.h, arr, float(seg_cost)))
+
     def set_mlp_mode(self, mode):
         """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check),
         2 = bf16x6 forward, three-product backward chain (experiment)."""
@@ -464,6 +499,8 @@ class AtlasFit:
         """HIP events around the launch classes in `mask`; `every` = P: only every P-th step of a train_steps call is timed (an event
         costs ~5 us in-stream)."""
         m = int(mask) if not isinstance(mask, bool) else (0xFFFF if mask else 0)
+        if not 1 <= int(every) <= 255:          # the period travels in bits 16..23 of af_set_timing's argument: 256 would wrap to "every step"
+            raise ValueError("set_timing: every must be 1..255, got %r" % (every,))
         self._chk(self.lib.af_set_timing(self.h, (m & 0xFFFF) | ((max(1, int(every)) & 0xFF) << 16)))
 
     def timing(self, reset=True):

@@ -83,7 +83,9 @@ struct BwdArgs {
 };
 
 // one launch = up to AF_MAX_NETS independent row-tile ranges ("parts"), see mlp.hip
-// wg_stamp (optional, af_debug_step_clocks): [gridDim.x][4] = s_memrealtime (100 MHz) and s_memtime (shader clock) at workgroup start, then at its end
+#define AF_STAMP_WG 4096      // workgroups per launch the stamp buffer holds; workgroups beyond it are not stamped (a launch of the shipped sizes has at most ~1200;
+                              // samples_batch 100 000 has ~7 000 single / ~18 000 two-layer)
+// wg_stamp (optional, af_debug_step_clocks): [min(gridDim.x, AF_STAMP_WG)][4] = s_memrealtime (100 MHz) and s_memtime (shader clock) at workgroup start, then at its end
 struct MultiFwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; FwdArgs a[AF_MAX_NETS]; unsigned long long* wg_stamp; };
 struct MultiBwd { int n; int net[AF_MAX_NETS]; int wg_end[AF_MAX_NETS]; BwdArgs a[AF_MAX_NETS]; int nprod; unsigned long long* wg_stamp; };      // nprod: 3 selects the three-product chain (mlpbf.hip)
 
@@ -107,6 +109,9 @@ struct DwArgs {
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+// af_debug_step_clocks: both counters at workgroup start (i = 0) and end (i = 1) - s_memtime ticks over the s_memrealtime span = the
+// clock the CU's issue follows while this launch runs INSIDE the step (one scalar compare per workgroup when off)
+#define AF_STAMP(m, i) if ((m).wg_stamp && threadIdx.x == 0 && blockIdx.x < AF_STAMP_WG) { (m).wg_stamp[blockIdx.x * 4 + 2 * (i)] = __builtin_amdgcn_s_memrealtime(); (m).wg_stamp[blockIdx.x * 4 + 2 * (i) + 1] = __builtin_amdgcn_s_memtime(); }
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
 typedef float    f32x4  __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
 #else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (a.wg_stamp && tid == 0) { a.wg_stamp[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime(); a.wg_stamp[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); }
+  if (a.wg_stamp && tid == 0 && blockIdx.x < AF_STAMP_WG) { a.wg_stamp[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime(); a.wg_stamp[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); }
   for (int s = 0; s < DW_MAXSEG; ++s) {
     DwSeg sg = dw_uniform(segs[s]);
     if (sg.job < 0) break;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf(DwArgs a) {
 #else
   if (a.wg_clock && tid == 0) a.wg_clock[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (a.wg_stamp && tid == 0) { a.wg_stamp[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime(); a.wg_stamp[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime(); }
+  if (a.wg_stamp && tid == 0 && blockIdx.x < AF_STAMP_WG) { a.wg_stamp[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime(); a.wg_stamp[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime(); }
 }
 
 __global__ __launch_bounds__(256, 1) void k_dw(DwArgs a) {

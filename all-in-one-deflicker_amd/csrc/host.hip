@@ -6,6 +6,7 @@
 // No host synchronisation inside the loop; the host only enqueues.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
@@ -116,6 +117,7 @@ struct af_handle {
   std::vector<double> frame_sse; std::vector<char> frame_sse_valid;
   bool debug = false; unsigned timing = 0, timing_every = 1; bool timing_live = true;   // timing_every: af_set_timing's sample period; timing_live: this step of af_train_steps is a sampled one
   double flop_fwd[AF_MAX_NETS] = {0}, flop_dx[AF_MAX_NETS] = {0};     // algorithmic FLOPs per MLP row of each net as built (forward == dW; dX chain), BASELINE.md 3
+  bool dw_cost_set = false; double dw_cost[5] = {0}, dw_seg_cost = 0;      // af_debug_set_dw_cost: an explicit tile-cost row for build_sched (validated there: finite, > 0)
   int dw_mode = 1;                            // k_dw arithmetic (dw.hip): 1 = bf16x6 (fp32-faithful, the default), 2 = bf16x3 (hi + mid bf16 per operand, three products; opt-in), 0 = fp32 MFMA
   std::vector<TimedEv> evs; double t_ms[16] = {0}, t_flops[16] = {0}; long long t_cnt[16] = {0};
 
@@ -318,9 +320,9 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
   double seg_cost = 60.0;
   double cost_row[5];
   for (int i = 0; i < 5; ++i) cost_row[i] = kTileCost[h->dw_mode][i];
-  if (const char* e_ = getenv("AF_DW_COST")) {     // experiments only (tools/dw_cost_sweep.sh): "c8x8,c8x2,c8x1,c1x8,c1x2[,seg]" replaces the row of the current arithmetic
-    double v_[6]; const int n_ = sscanf(e_, "%lf,%lf,%lf,%lf,%lf,%lf", v_, v_ + 1, v_ + 2, v_ + 3, v_ + 4, v_ + 5);
-    if (n_ >= 5) { for (int i = 0; i < 5; ++i) cost_row[i] = v_[i]; if (n_ == 6) seg_cost = v_[5]; }
+  if (h->dw_cost_set) {     // af_debug_set_dw_cost (experiments and the partition-sensitivity tests): replaces the row of the current arithmetic
+    for (int i = 0; i < 5; ++i) cost_row[i] = h->dw_cost[i];
+    if (h->dw_seg_cost > 0) seg_cost = h->dw_seg_cost;
   }
   auto tile_cost = [&](int j) { return cost_row[sc.jobs[j].shape]; };
   double work = 0;
@@ -496,7 +498,6 @@ bool glob_on(const af_config& c, int iter) { return c.include_global_rigidity_lo
 // rows of a part that carry real data (the last tile of a net may be padded)
 double part_rows(int tile0, int NT, int rows_total) { return (double)std::max(0, std::min(NT * 32, rows_total) - tile0 * 32); }
 
-#define AF_STAMP_WG 4096      // workgroups per launch the stamp buffer holds (a launch of the shipped sizes has at most ~1200)
 struct FwdPart { int net; FwdArgs a; int rows_total; };
 struct BwdPart { int net; BwdArgs a; int rows_total; };
 
@@ -791,10 +792,8 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (e != hipSuccess) { g_create_error = std::string("af_create: hipSetDevice: ") + hipGetErrorString(e); return AF_EHIP; }
   af_handle* h = new af_handle();
   h->cfg = *cfg; h->device = device_ordinal; h->seg = seg;
-  if (const char* e_ = getenv("AF_DW_FP32")) h->dw_mode = atoi(e_) ? 0 : h->dw_mode;
-  if (const char* e_ = getenv("AF_DW_MODE")) { const int m_ = atoi(e_); if (m_ >= 0 && m_ <= 2) h->dw_mode = m_; }
-  if (const char* e_ = getenv("AF_MLP_FP32")) h->mlp_mode = atoi(e_) ? 0 : 1;
-  if (const char* e_ = getenv("AF_MLP_MODE")) { const int m_ = atoi(e_); if (m_ >= 0 && m_ <= 2) h->mlp_mode = m_; }
+  // no environment is read here: the arithmetic modes and the tile-cost row are set through af_set_mlp_mode / af_set_dw_mode / af_debug_set_dw_cost
+  // (the Python mirror maps AF_MLP_MODE, AF_DW_MODE, AF_MLP_FP32, AF_DW_FP32, AF_DW_COST onto those calls for the A/B tools)
   if (h->cfg.pretrain_batch <= 0) h->cfg.pretrain_batch = 10000;
   if (h->cfg.lr <= 0) h->cfg.lr = 1e-4f;
   auto die = [&](int code) { g_create_error = h->err; af_destroy(h); return code; };
@@ -1008,12 +1007,9 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
   return AF_OK;
 }
 
-int af_set_dw_mode(af_handle* h, int mode) {
-  if (!h) return AF_EINVAL;
-  if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
-  if (mode == h->dw_mode) return AF_OK;
+// Re-cut every split-K schedule (loop and pre-train) for the current arithmetic / cost row and upload it.
+static int rebuild_dw_scheds(af_handle* h) {
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
-  h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic: re-cut every schedule (loop and pre-train)
   bool ok = build_main_scheds(h);
   ok = ok && build_sched(h, h->sched[2], {{&h->nets[AF_NET_MAP1], tiles_of(h->cfg.pretrain_batch)}});
   if (h->seg) ok = ok && build_sched(h, h->sched[3], {{&h->nets[AF_NET_MAP2], tiles_of(h->cfg.pretrain_batch)}});
@@ -1026,6 +1022,34 @@ int af_set_dw_mode(af_handle* h, int mode) {
     }
   }
   return AF_OK;
+}
+int af_set_dw_mode(af_handle* h, int mode) {
+  if (!h) return AF_EINVAL;
+  if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_dw_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
+  if (mode == h->dw_mode) return AF_OK;
+  h->dw_mode = mode;                       // the tile costs of the split-K schedule belong to the arithmetic
+  return rebuild_dw_scheds(h);
+}
+int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost) {
+  if (!h) return AF_EINVAL;
+  if (!cost5) { if (!h->dw_cost_set) return AF_OK; h->dw_cost_set = false; h->dw_seg_cost = 0; return rebuild_dw_scheds(h); }
+  for (int i = 0; i < 5; ++i)
+    if (!(cost5[i] > 0.0) || !std::isfinite(cost5[i])) return h->fail(AF_EINVAL, "af_debug_set_dw_cost: every tile cost must be finite and > 0");
+  if (std::isnan(seg_cost) || std::isinf(seg_cost)) return h->fail(AF_EINVAL, "af_debug_set_dw_cost: seg_cost must be finite (<= 0 keeps the shipped one)");
+  const double r = *std::max_element(cost5, cost5 + 5) / *std::min_element(cost5, cost5 + 5);
+  if (r > 1.0e3) return h->fail(AF_EINVAL, "af_debug_set_dw_cost: cost ratios beyond 1000:1 cut segments the DW_MAXSEG lists cannot hold");
+  double keep[5]; const bool was = h->dw_cost_set; const double keep_seg = h->dw_seg_cost;
+  for (int i = 0; i < 5; ++i) { keep[i] = h->dw_cost[i]; h->dw_cost[i] = cost5[i]; }
+  h->dw_cost_set = true; h->dw_seg_cost = seg_cost > 0 ? seg_cost : 0;
+  const int rc = rebuild_dw_scheds(h);
+  if (rc != AF_OK) {                      // a row the segment lists cannot hold: back to what was there, the handle stays usable
+    const std::string msg = h->err;
+    for (int i = 0; i < 5; ++i) h->dw_cost[i] = keep[i];
+    h->dw_cost_set = was; h->dw_seg_cost = keep_seg;
+    (void)rebuild_dw_scheds(h);
+    h->err = msg;
+  }
+  return rc;
 }
 int af_set_mlp_mode(af_handle* h, int mode) {
   if (!h) return AF_EINVAL;
@@ -1242,7 +1266,7 @@ int af_debug_step_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg) {
   }
   if (h->step_stamp) HCHK(hipMemset(h->step_stamp, 0, n * 8));      // a launch smaller than the last one leaves zeros, not old stamps
   if (!enable && h->step_stamp) { (void)hipFree(h->step_stamp); h->step_stamp = nullptr; }
-  return AF_STAMP_WG;
+  return AF_STAMP_WG;      // the cap, NOT the grid size: workgroups beyond it are not stamped (the kernels test blockIdx.x < AF_STAMP_WG), rows of zeros are workgroups a launch did not have
 }
 
 int af_debug_dw_schedule(af_handle* h, int which, int32_t* out, int cap_wg) {

@@ -293,6 +293,7 @@ AF_DEV void mlp_bwd_body(const BwdArgs& a, int wg, char* smem) {
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi(MultiFwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  AF_STAMP(m, 0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -303,10 +304,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi(MultiFwd m) {
     case AF_KIND_MAP_PE: if (m.a[s].nl > 2) mlp_fwd_body<NsMapPe, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsMapPe, TRAIN, false>(m.a[s], wg - base, smem); break;
     default:           if (m.a[s].nl > 2) mlp_fwd_body<NsAlpha, TRAIN, true>(m.a[s], wg - base, smem); else mlp_fwd_body<NsAlpha, TRAIN, false>(m.a[s], wg - base, smem); break;
   }
+  AF_STAMP(m, 1);
 }
 
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi(MultiBwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  AF_STAMP(m, 0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi(MultiBwd m) {
     case AF_KIND_MAP_PE: mlp_bwd_body<NsMapPe>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body<NsAlpha>(m.a[s], wg - base, smem); break;
   }
+  AF_STAMP(m, 1);
 }
 
 // wg_end[] is filled here from the parts' tile ranges

@@ -610,9 +610,6 @@ __device__ unsigned long long* g_af_clk;
 #else
 #define AF_CLK_MARK(i)
 #endif
-// af_debug_step_clocks: both counters at workgroup start (i = 0) and end (i = 1) - s_memtime ticks over the s_memrealtime span = the
-// clock the CU's issue follows while this launch runs INSIDE the step (one scalar compare per workgroup when off)
-#define AF_STAMP(m, i) if ((m).wg_stamp && threadIdx.x == 0) { (m).wg_stamp[blockIdx.x * 4 + 2 * (i)] = __builtin_amdgcn_s_memrealtime(); (m).wg_stamp[blockIdx.x * 4 + 2 * (i) + 1] = __builtin_amdgcn_s_memtime(); }
 
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_bf(MultiFwd m) {
@@ -654,6 +651,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf(MultiBwd m) {
 // the same chain on three products (see bf_kstep)
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf3(MultiBwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  AF_STAMP(m, 0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -664,6 +662,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_bf3(MultiBwd m) {
     case AF_KIND_MAP_PE: mlp_bwd_body_bf<NsMapPe, 3>(m.a[s], wg - base, smem); break;
     default:           mlp_bwd_body_bf<NsAlpha, 3>(m.a[s], wg - base, smem); break;
   }
+  AF_STAMP(m, 1);
 }
 
 extern "C" int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s) {

@@ -158,6 +158,36 @@ def load_input_data_single(resy, resx, maximum_number_of_frames, data_folder, fi
     return optical_flows_mask, video_frames, optical_flows_reverse_mask, optical_flows_reverse, optical_flows
 
 
+def _prefetch(fn, items, workers=8, depth=16):
+    """fn(item) for every item, in order, computed by a thread pool at most `depth` items ahead of the consumer: PIL's decoders,
+    zlib and np.load release the GIL, so file decoding runs on the host's cores while the caller feeds the GPU (a 200-frame 1080p
+    clip would not fit in memory decoded all at once, hence the bound)."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        q, it = deque(), iter(items)
+        for x in it:
+            q.append(ex.submit(fn, x))
+            if len(q) >= depth:
+                break
+        while q:
+            r = q.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                q.append(ex.submit(fn, nxt))
+            yield r
+
+
+def count_input_frames(maximum_number_of_frames, data_folder):
+    """F as load_input_data_single computes it (unwrap_utils.py:110,112), without decoding anything."""
+    data_folder = Path(data_folder)
+    n = len(list(data_folder.glob("*.jpg")) + list(data_folder.glob("*.png")))
+    if not n:
+        raise FileNotFoundError("no *.jpg / *.png frames under %s" % data_folder)
+    return int(np.minimum(maximum_number_of_frames, n))
+
+
 def load_input_data_device(resy, resx, maximum_number_of_frames, data_folder, filter_optical_flow, vid_root, vid_name,
                            with_masks=False, device=0):
     """load_input_data_single / load_input_data (unwrap_utils.py:40-163) with the per-pixel work on the GPU: files
@@ -198,15 +228,19 @@ def load_input_data_device(resy, resx, maximum_number_of_frames, data_folder, fi
             im = np.tile(im[:, :, None], [1, 1, 3]) if im.ndim == 2 else im[:, :, :3]
         else:
             im = im[:, :, None] if im.ndim == 2 else im[:, :, :1]
-        return torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+        return np.ascontiguousarray(im)
 
-    for i in range(F):
-        resize_bilinear_device(u8(input_files[i], 3), video_frames, resy, resx, 3 * F, F, i, device=device)
+    # decode on a thread pool (round 5: 160 serial PIL / np.load calls were ~3 s of the CLI's wall clock), feed the GPU in file order
+    def dec_frame(i):
+        return u8(input_files[i], 3), (u8(mask_files[i], 1) if with_masks else None)
+
+    for i, (im, mk) in enumerate(_prefetch(dec_frame, range(F))):
+        resize_bilinear_device(torch.from_numpy(im).to(dev), video_frames, resy, resx, 3 * F, F, i, device=device)
         if with_masks:
-            resize_bilinear_device(u8(mask_files[i], 1), mask_frames, resy, resx, F, 0, i, device=device)
+            resize_bilinear_device(torch.from_numpy(mk).to(dev), mask_frames, resy, resx, F, 0, i, device=device)
 
-    def flow(path):
-        f = torch.from_numpy(np.ascontiguousarray(np.load(path).astype(np.float32))).to(dev)
+    def flow(arr):
+        f = torch.from_numpy(arr).to(dev)
         if f.shape[0] != resy or f.shape[1] != resx:
             oldh, oldw = f.shape[0], f.shape[1]
             r = torch.empty((resy, resx, 2), device=dev)
@@ -214,12 +248,15 @@ def load_input_data_device(resy, resx, maximum_number_of_frames, data_folder, fi
             f = r
         return f
 
-    for i in range(F - 1):
+    def dec_flows(i):
         fn1, fn2 = input_files[i].name, input_files[i + 1].name
         f12p, f21p = out_flow_dir / f"{fn1}_{fn2}.npy", out_flow_dir / f"{fn2}_{fn1}.npy"
         if not f12p.exists() or not f21p.exists():
             raise FileNotFoundError("optical flow %s missing: run the reference's src/preprocess_optical_flow.py first" % f12p)
-        f12, f21 = flow(f12p), flow(f21p)
+        return tuple(np.ascontiguousarray(np.load(q).astype(np.float32)) for q in (f12p, f21p))
+
+    for i, (a12, a21) in enumerate(_prefetch(dec_flows, range(F - 1), depth=8)):
+        f12, f21 = flow(a12), flow(a21)
         optical_flows[:, :, :, i] = f12
         optical_flows_reverse[:, :, :, i + 1] = f21
         if filter_optical_flow:
@@ -306,12 +343,21 @@ def evaluate_model_single(af, video_frames, results_folder, iteration, save_chec
         save_checkpoint(af, results_folder / "checkpoint", iteration)
         if af.two_layer:                                   # evaluate.py:224-232 keeps a second copy per evaluation
             save_checkpoint(af, eval_dir / "checkpoint", iteration)
+    from concurrent.futures import ThreadPoolExecutor
     F = video_frames.shape[3]
     psnrs = np.zeros(F)
-    for f in range(F):
-        rec, sse = af.render_frame(f)
+
+    def write(f, rec):      # the reference's truncating uint8 cast (evaluate.py:732-733); zlib releases the GIL, the encodes run beside the renders
         Image.fromarray((rec.astype(np.float64) * 255).astype(np.uint8)).save(str(results_folder / "output" / ("%05d.png" % f)))
-        psnrs[f] = 10.0 * np.log10(1.0 / (sse / rec.size))
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        jobs = []
+        for f in range(F):
+            rec, sse = af.render_frame(f)
+            jobs.append(ex.submit(write, f, rec))
+            psnrs[f] = 10.0 * np.log10(1.0 / (sse / rec.size))
+        for j in jobs:
+            j.result()
     print(psnrs.mean())
     open(eval_dir / ("PSNR_%f" % psnrs.mean()), "a").close()
     return float(psnrs.mean())
@@ -337,20 +383,15 @@ def main(config, args, two_layer=False):
     results_folder.mkdir(parents=True, exist_ok=True)
     with open(results_folder / "config.json", "w") as f:
         json.dump(config, f, indent=4)
-    if getattr(args, "host_loader", False):      # the numpy restatement of the reference loader (slow; kept as the cross-check)
-        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
-            resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
-        mask_frames = load_mask_frames(resy, resx, video_frames.shape[3], vid_root, vid_name) if two_layer else None
-    else:
-        t = load_input_data_device(resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name,
-                                   with_masks=two_layer, device=getattr(args, "device_ordinal", 0))
-        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
-        mask_frames = t[5] if two_layer else None
-    F = video_frames.shape[3]
-    af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=getattr(args, "device_ordinal", 0))
-    af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask, mask_frames)
     import math
+    import threading
+    import time
     import torch
+    t_wall = [("start", time.perf_counter())]
+    mark = lambda name: t_wall.append((name, time.perf_counter()))
+    dev_ord = getattr(args, "device_ordinal", 0)
+    F = count_input_frames(config["maximum_number_of_frames"], data_folder)
+    af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=dev_ord)
     # Random draws: the reference uses torch's process-global RNG.  With --seed (an extension) every draw of this call comes
     # from its own torch.Generator, so concurrent videos in one process (launch_videos.py --concurrent) stay reproducible
     # and independent; without it the global RNG is used like the reference does.
@@ -358,6 +399,7 @@ def main(config, args, two_layer=False):
     gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
     draw = lambda: int(torch.randint(2 ** 31, (1,), generator=gen))
     start_iteration = 0
+    pre = None
     if not config["load_checkpoint"]:
         # nn.Linear default init in the reference's construction order (:112-128; seg :127-161 mapping1, mapping2, atlas, alpha)
         order = (A.NET_MAPPING1, A.NET_MAPPING2, A.NET_ATLAS, A.NET_ALPHA) if two_layer else (A.NET_MAPPING1, A.NET_ATLAS)
@@ -370,12 +412,47 @@ def main(config, args, two_layer=False):
                 torch.nn.init.uniform_(b, -bound, bound, generator=gen)
                 sd["hidden.%d.weight" % i] = w; sd["hidden.%d.bias" % i] = b
             af.load_state_dict(net, sd)
+        # pre_train_mapping reads nothing of the video (unwrap_utils.py:176-198: random pixel coordinates of frame f against uv = 0.8 xy;
+        # asserted in oracle/make_golden.py), so it starts NOW, on the handle's stream from its own thread (ctypes drops the GIL), while this
+        # thread decodes, resizes and uploads the clip: 1.7 s (single) / 3.3 s (fg/bg) of the schedule leave the critical path (round 5).
+        # The draws keep the reference's order: init, pre-train seed(s), sampler seed.
+        jobs = []
         if config["pretrain_mapping1"]:
             print("pre-training")
-            af.pre_train_mapping(config["pretrain_iter_number"], seed=draw())
+            jobs.append((draw(), A.NET_MAPPING1))
         if two_layer and config["pretrain_mapping2"]:
-            af.pre_train_mapping(config["pretrain_iter_number"], seed=draw(), net=A.NET_MAPPING2)
+            jobs.append((draw(), A.NET_MAPPING2))
+        err = []
+
+        def pretrain():
+            try:
+                for sd_, net in jobs:
+                    af.pre_train_mapping(config["pretrain_iter_number"], seed=sd_, net=net)
+            except BaseException as e:      # surfaces in the main thread at join
+                err.append(e)
+        pre = threading.Thread(target=pretrain, name="af-pretrain")
+        pre.start()
+    mark("handle + init")
+    if getattr(args, "host_loader", False):      # the numpy restatement of the reference loader (slow; kept as the cross-check)
+        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
+            resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
+        mask_frames = load_mask_frames(resy, resx, video_frames.shape[3], vid_root, vid_name) if two_layer else None
     else:
+        t = load_input_data_device(resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name,
+                                   with_masks=two_layer, device=dev_ord)
+        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
+        mask_frames = t[5] if two_layer else None
+    assert video_frames.shape[3] == F
+    mark("input builder")
+    if pre is not None:
+        pre.join()
+        if err:
+            af.close()
+            raise err[0]
+    mark("pre-train (overlapped) done")
+    af.upload_video(video_frames, flows, flows_rev, flows_mask, flows_rev_mask, mask_frames)
+    mark("table packed")
+    if config["load_checkpoint"]:
         start_iteration = load_checkpoint(af, config["checkpoint_path"])
     sampler_seed = draw()
     i = start_iteration
@@ -389,6 +466,9 @@ def main(config, args, two_layer=False):
         if stop % evaluate_every == 0 and stop > start_iteration:
             last_psnr = evaluate_model_single(af, video_frames, results_folder, stop)
     af.close()
+    mark("loop + evaluation")
+    if os.environ.get("AF_CLI_TIMING"):      # wall clock per stage of this process, for tools/cli_end_to_end.py
+        print("AF_CLI_TIMING " + json.dumps({n: round(t1 - t0, 3) for (_, t0), (n, t1) in zip(t_wall, t_wall[1:])}), file=sys.stderr)
     return last_psnr
 
 

@@ -555,6 +555,9 @@ def main():
     sampled = list(range(0, K, EVENT_EVERY))                         # the timed steps whose launches carried events (af_set_timing's period)
     inv_sampled = float((2 * N - nv[sampled].sum(axis=1)).sum())
     n_launch = max(sum(tk[c][1] for c in dom_classes), 1)
+    # the sample period restarts at k = 0 of every af_train_steps call and the timed region is ONE call: the launches counted by the library
+    # must be a whole number per sampled step, or `sampled` (and the masked FLOPs charged to it) no longer describes what was timed
+    assert n_launch % len(sampled) == 0 and n_launch // len(sampled) == len(dom_classes), (n_launch, len(sampled), dom_classes)
     launches_per_step = n_launch / len(sampled)
     dom_ms = sum(tk[c][0] for c in dom_classes) / n_launch
     is_dw = "dw" in dom_classes

@@ -134,9 +134,11 @@ int af_debug_plan(int ncu, int rows_map, int rows_atlas, int dep_rows, int out3[
  * end of each workgroup; out (nullable) receives [min(cap_wg, #CUs)][2] values of the most recent launch.  Returns #CUs. */
 int af_debug_dw_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
 /* The clock each hot kernel runs at INSIDE the training step: enable != 0 makes the five hot launches of every later step (forward 1, 2,
- * backward 1, 2 of the bf16 chains, k_dw) record per workgroup {s_memrealtime, s_memtime} at its start and at its end; out (nullable)
- * receives [5][min(cap_wg, 4096)][4] uint64 of the most recent step (zeros for workgroups a launch did not have) and the buffer is
- * cleared.  Ticks over the 100 MHz span = the shader clock under that launch's load (tools/step_clock.py).  Returns 4096. */
+ * backward 1, 2 of the chains in any mlp_mode, k_dw) record per workgroup {s_memrealtime, s_memtime} at its start and at its end; out
+ * (nullable) receives [5][min(cap_wg, 4096)][4] uint64 of the most recent step (zeros for workgroups a launch did not have) and the
+ * buffer is cleared.  Only the first 4096 workgroups of a launch are stamped (samples_batch 100 000 launches ~7 000 - 18 000; the rest
+ * are skipped, nothing is written past a launch's region).  Ticks over the 100 MHz span = the shader clock under that launch's load
+ * (tools/step_clock.py).  Returns 4096 (the cap, not a grid size). */
 int af_debug_step_clocks(af_handle* h, int enable, uint64_t* out, int cap_wg);
 /* The static split-K schedule of k_dw: which = 0 (9 row segments), 1 (7), 2 / 3 (pre-train of mapping1 / mapping2).
  * out (nullable) [min(cap_wg, #workgroups)][16][4] int32 = {job shape 0..4 (8x8, 8x2, 8x1, 1x8, 1x2; -1 ends a list), first row tile,
@@ -151,12 +153,19 @@ int af_debug_records(af_handle* h, const int64_t* inds, int n, float* out);
  * two bf16 values per operand (16 mantissa bits), three partial products: NARROWER than the reference's fp32, faster,
  * measured within 3x of torch-fp32's own gradient error against an fp64 twin at full size (tests/test_gpu_fullsize.py);
  * never the default and never bench.py's headline value.  0 = the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  The three
- * are held against each other in tests/test_gpu_dw_modes.py.  Env AF_DW_MODE=<m> at af_create; AF_DW_FP32=1 selects 0.
+ * are held against each other in tests/test_gpu_dw_modes.py.  The library reads no environment: the Python mirror maps
+ * AF_DW_MODE=<m> / AF_DW_FP32=1 onto this call for the A/B tools.
  * A switch re-cuts all split-K schedules (their tile costs belong to the arithmetic). */
 int af_set_dw_mode(af_handle* h, int mode);
+/* Experiments and the partition-sensitivity tests: replace the per-shape tile costs k_dw's static split-K schedule is cut with
+ * (cost5 = 8x8, 8x2, 8x1, 1x8, 1x2 tiles; every value finite and > 0, ratios <= 1000:1; seg_cost <= 0 keeps the shipped per-segment
+ * cost) and re-cut all schedules; cost5 == NULL returns to the shipped row of the current arithmetic.  Another row = another
+ * partition of the row batch over workgroups = another summation ORDER of the same partial products, nothing else; results stay
+ * bit-reproducible for a given row.  AF_EINVAL (handle unchanged) for a row that is not valid or cannot be scheduled. */
+int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost);
 /* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
  * = bf16x6, 0 = fp32 matrix pipe, 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16
- * operands — a measured experiment, not a default.  Env AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.
+ * operands — a measured experiment, not a default.  (Python mirror: AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.)
  * pre_train_mapping's MLP chains always run the fp32 16-row kernels (mlp16.hip); its weight-gradient GEMM follows af_set_dw_mode. */
 int af_set_mlp_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */

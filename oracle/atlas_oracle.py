@@ -306,7 +306,8 @@ def compute_consistency(flow12, flow21):
 # ------------------------------------------------------------------------------------------------
 def field_motion(rng_uniform, nframes, resx, resy):
     """Per-frame similarity motion + flow-error bumps of the `flow="field"` videos.  `rng_uniform(lo, hi, n)` draws; the order
-    of the draws is part of the video's definition (bench.synth_video_device feeds a torch generator through the same code)."""
+    of the draws is part of the video's definition.  (bench._synth_video_field_device builds the same KIND of video on the device from its
+    own torch-generator draws — bench.py's timed path may not import oracle/ — so the two videos are alike, not identical.)"""
     n = nframes - 1
     m = float(min(resx, resy))
     return dict(theta=rng_uniform(-0.008, 0.008, n), zoom=rng_uniform(0.994, 1.006, n), tx=rng_uniform(-2.0, 2.0, n), ty=rng_uniform(-1.2, 1.2, n),

@@ -96,7 +96,18 @@ def _grad64_step(models32, twins64, video64, i, jif, c, opt):
     return terms
 
 
-def run_seed(seed, c, double=False, flow="constant", grad64=False):
+def _save_partial(path, seed, flow, curve, psnr_at, t_pre, t_loop, psnr_pre):
+    """configs[1] runs take hours: what the run has produced so far is written after every logged iteration, so that an
+    interrupted run still leaves the loss curve and the intermediate PSNRs behind (tests/test_gpu_c2.py accepts a partial file)."""
+    tmp = path + ".tmp.npz"
+    np.savez_compressed(tmp, seed=seed, flow_kind=flow, resx=RESX, resy=RESY, nframes=NF, iters=ITERS, log_every=LOG_EVERY,
+                        curve=np.array(curve, np.float64), psnr_at_iter=np.array([k for k, _ in psnr_at], np.int64),
+                        psnr_at=np.array([v for _, v in psnr_at], np.float64), psnr_pre=psnr_pre,
+                        cpu_seconds=np.array([t_pre, t_loop]), threads=torch.get_num_threads(), complete=False)
+    os.replace(tmp, path)
+
+
+def run_seed(seed, c, double=False, flow="constant", grad64=False, psnr_iters=(), partial=None):
     video = O.synthetic_video(RESX, RESY, NF, seed=seed, flow=flow)
     torch.manual_seed(seed)
     # stage1_neural_atlas.py:112-128 (mapping first, then atlas)
@@ -124,9 +135,14 @@ def run_seed(seed, c, double=False, flow="constant", grad64=False):
     psnr_pre, _ = O.mean_psnr(rm, ra, video)
     jif_all = get_tuples(NF, video.video_frames)
     N = c["samples_batch"]
-    curve = []
+    curve, psnr_at, t_eval = [], [], 0.0
     t0 = time.time()
     for i in range(ITERS):
+        if i in psnr_iters:     # PSNR of the state BEFORE iteration i (i.e. after i iterations), outside the draw stream: rendering draws nothing
+            te = time.time()
+            psnr_at.append((i, O.mean_psnr(rm, ra, video)[0]))
+            t_eval += time.time() - te
+            print("seed %d: PSNR %.4f dB after %d iterations" % (seed, psnr_at[-1][1], i), flush=True)
         inds = torch.randint(jif_all.shape[1], (np.int64(N * 1.0), 1))
         if grad64:
             terms = _grad64_step((rm, ra), twins, video64, i, jif_all[:, inds], c, opt)
@@ -136,10 +152,13 @@ def run_seed(seed, c, double=False, flow="constant", grad64=False):
         if i % LOG_EVERY == 0:
             curve.append(terms)
             print("seed %d iter %4d  total %.4f  rgb %.5f  (%.0f s)" % (seed, i, terms[5], terms[0], time.time() - t0), flush=True)
-    t_loop = time.time() - t0
+            if partial:
+                _save_partial(partial, seed, flow, curve, psnr_at, t_pre, time.time() - t0 - t_eval, psnr_pre)
+    t_loop = time.time() - t0 - t_eval
     psnr, per = O.mean_psnr(rm, ra, video)
     print("seed %d: PSNR %.4f dB after the pre-train -> %.4f dB after %d iterations (pre-train %.0f s, loop %.0f s)" % (seed, psnr_pre, psnr, ITERS, t_pre, t_loop), flush=True)
     return dict(psnr_pre=psnr_pre, psnr=psnr, per_frame=np.array(per), curve=np.array(curve, np.float64), t_pre=t_pre, t_loop=t_loop,
+                psnr_at_iter=np.array([k for k, _ in psnr_at], np.int64), psnr_at=np.array([v for _, v in psnr_at], np.float64),
                 video_checksum=float(video.video_frames.double().sum()))
 
 
@@ -152,7 +171,15 @@ def main():
     ap.add_argument("--merge", nargs="+", default=None, help="stack per-seed files written by earlier invocations into --out (thread counts and flow kinds are kept per seed)")
     ap.add_argument("--grad64", action="store_true", help="fp32 weights, Adam state and draws; the gradient of every loop iteration from an fp64 twin (diagnostic: is torch-fp32's gradient round-off what separates the reference from the HIP path?)")
     ap.add_argument("--flow", default="constant", choices=["constant", "field"], help="round 4: 'field' = oracle.atlas_oracle.synthetic_video(flow='field'), a per-pixel, per-frame flow field with holed masks")
+    ap.add_argument("--resx", type=int, default=RESX)
+    ap.add_argument("--resy", type=int, default=RESY)
+    ap.add_argument("--nframes", type=int, default=NF)
+    ap.add_argument("--iters", type=int, default=ITERS, help="round 5: 10001 with --resx 768 --resy 432 = BASELINE configs[1], the shipped iters_num (config_flow_100.json:6)")
+    ap.add_argument("--log-every", type=int, default=LOG_EVERY)
+    ap.add_argument("--psnr-at", type=int, nargs="*", default=[], help="also render + PSNR after this many loop iterations (e.g. 5000 = where global rigidity stops, config_flow_100.json:44)")
+    ap.add_argument("--partial", default=None, help="write the curve / PSNRs so far to this file after every logged iteration")
     args = ap.parse_args()
+    globals().update(RESX=args.resx, RESY=args.resy, NF=args.nframes, ITERS=args.iters, LOG_EVERY=args.log_every)
     if args.merge:
         parts = [dict(np.load(f)) for f in args.merge]
         parts.sort(key=lambda d: int(d["seeds"][0]))
@@ -163,7 +190,10 @@ def main():
             d["flow_kind"] = d.get("flow_kind", np.array(["constant"] * n))
         out = {k: parts[0][k] for k in ("resx", "resy", "nframes", "iters", "pretrain_iters", "log_every")}
         out["threads"] = parts[0]["threads"] if len({int(d["threads"]) for d in parts}) == 1 else np.int64(-1)
-        for k in ("seeds", "psnr_pre", "psnr", "psnr_per_frame", "curves", "cpu_seconds", "video_checksum", "threads_per_seed", "flow_kind"):
+        keys = ["seeds", "psnr_pre", "psnr", "psnr_per_frame", "curves", "cpu_seconds", "video_checksum", "threads_per_seed", "flow_kind"]
+        if all("psnr_at" in d for d in parts):
+            keys += ["psnr_at"]; out["psnr_at_iter"] = parts[0]["psnr_at_iter"]
+        for k in keys:
             out[k] = np.concatenate([d[k] for d in parts], axis=0)
         np.savez_compressed(args.out, **out)
         print("merged", [int(x) for x in out["seeds"]], "->", args.out, "PSNR", np.array2string(out["psnr"], precision=3))
@@ -171,7 +201,7 @@ def main():
     if args.threads > 0:
         torch.set_num_threads(args.threads)
     c = shipped_config()
-    res = [run_seed(s, c, args.double, args.flow, args.grad64) for s in args.seeds]
+    res = [run_seed(s, c, args.double, args.flow, args.grad64, tuple(args.psnr_at), args.partial) for s in args.seeds]
     np.savez_compressed(
         args.out, seeds=np.array(args.seeds), resx=RESX, resy=RESY, nframes=NF, iters=ITERS, pretrain_iters=PRETRAIN_ITERS, log_every=LOG_EVERY,
         psnr_pre=np.array([r["psnr_pre"] for r in res]), psnr=np.array([r["psnr"] for r in res]),
@@ -179,6 +209,7 @@ def main():
         cpu_seconds=np.array([[r["t_pre"], r["t_loop"]] for r in res]), threads=torch.get_num_threads(),
         video_checksum=np.array([r["video_checksum"] for r in res]),
         threads_per_seed=np.full(len(res), torch.get_num_threads()), flow_kind=np.array([args.flow] * len(res)),
+        psnr_at_iter=res[0]["psnr_at_iter"], psnr_at=np.stack([r["psnr_at"] for r in res]),
     )
     print("written", args.out, "PSNR", [r["psnr"] for r in res])
 

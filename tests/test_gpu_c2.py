@@ -1,0 +1,161 @@
+"""BASELINE configs[1] — the headline config — end to end against the REFERENCE's own modules: 80 frames
+768x432, pre_train_mapping 100 x F = 8000 steps, iters_num 10001 of the shipped config (config_flow_100.json:6,44), i.e. 5001
+iterations with the global-rigidity rows and 5000 without them (stage1_neural_atlas.py:151-231,246-251).
+
+tests/golden/c2_reference.npz is written by `oracle/make_golden_c1.py --resx 768 --resy 432 --iters 10001 --log-every 250 --psnr-at 5000`
+in the build container (the reference's IMLP / loss functions / pre_train_mapping / torch.optim.Adam, ~6 h of CPU per seed on two
+threads): per seed the PSNR after the pre-train, after 5000 iterations, at the end, and the six loss terms every 250 iterations.
+Seeds 0 and 2 run on the translating video, seed 1 on the video whose flow differs at every pixel of every frame (holed masks).
+While a reference run is still going its `--partial` file (tests/golden/c2_partial_seed<k>.npz: the curve and PSNRs so far) is
+accepted in place of the complete record and everything it already holds is compared.
+
+Every random draw of the reference run came from torch's global CPU generator in the reference's order and is replayed here from
+the seed alone (as in test_gpu_c1.py).  The two fp32 trajectories decorrelate over 18 000 Adam steps; what must agree is where they
+pass and where they end.  No second reference arm exists at this size (6 h each), so the run-to-run sigma the tolerances need is
+measured on THIS side — every seed is run on three split-K partitions of the weight-gradient GEMM (af_debug_set_dw_cost: another
+summation order, nothing else) — and assumed for the reference as well (at configs[0] the reference's sigma was measured: 0.23 dB
+against this path's 0.2-0.3 dB; at configs[4] 0.22 against 0.37 dB).  BASELINE.md's 0.1 dB is asserted on top of two standard
+errors built from that sigma, per seed and on the mean over seeds, and the signed paired differences are printed with their SE."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COMPLETE = os.path.join(GOLD, "c2_reference.npz")
+PARTITIONS = (None, "306,150,126,129,87", "306,170,145,148,100")
+TERMS = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
+
+
+def _records():
+    """{seed: dict(flow, psnr_pre, psnr_at {iteration: dB}, psnr_end or None, curve (n, 6), every, iters, resx, resy, nframes, checksum or None)}"""
+    recs = {}
+    if os.path.exists(COMPLETE):
+        g = dict(np.load(COMPLETE))
+        for k, s in enumerate(g["seeds"]):
+            at = {int(i): float(p) for i, p in zip(g["psnr_at_iter"], g["psnr_at"][k])} if "psnr_at" in g else {}
+            recs[int(s)] = dict(flow=str(g["flow_kind"][k]), psnr_pre=float(g["psnr_pre"][k]), psnr_at=at, psnr_end=float(g["psnr"][k]),
+                                curve=g["curves"][k], every=int(g["log_every"]), iters=int(g["iters"]), resx=int(g["resx"]), resy=int(g["resy"]),
+                                nframes=int(g["nframes"]), checksum=float(g["video_checksum"][k]), cpu_seconds=g["cpu_seconds"][k])
+    for f in sorted(glob.glob(os.path.join(GOLD, "c2_partial_seed*.npz"))):
+        p = dict(np.load(f)); s = int(p["seed"])
+        if s in recs:
+            continue
+        recs[s] = dict(flow=str(p["flow_kind"]), psnr_pre=float(p["psnr_pre"]), psnr_at={int(i): float(v) for i, v in zip(p["psnr_at_iter"], p["psnr_at"])},
+                       psnr_end=None, curve=p["curve"], every=int(p["log_every"]), iters=int(p["iters"]), resx=int(p["resx"]), resy=int(p["resy"]),
+                       nframes=int(p["nframes"]), checksum=None, cpu_seconds=p["cpu_seconds"])
+    return recs
+
+
+def _video(seed, rec):
+    from oracle import atlas_oracle as O
+    v = O.synthetic_video(rec["resx"], rec["resy"], rec["nframes"], seed=seed, flow=rec["flow"])
+    if rec["checksum"] is not None:
+        assert abs(float(v.video_frames.double().sum()) - rec["checksum"]) < 1e-6 * rec["checksum"]
+    return v
+
+
+def _run(seed, rec, partition, upto, v):
+    """The HIP path on the reference run's video, initial weights and draws: PSNR after the pre-train, at the reference's intermediate
+    evaluations, at the end (None when `upto` stops earlier), and the loss terms of every iteration up to `upto`."""
+    import aiod_amd
+    import bench
+    resx, resy, F = rec["resx"], rec["resy"], rec["nframes"]
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(resx, resy, F))
+    if partition is not None:
+        af.set_dw_cost(partition)
+    af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
+    sds = bench.init_state_dicts(seed)                      # torch.manual_seed(seed) + nn.Linear init, mapping then atlas
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    N, P = af.N, F * resx * resy
+    steps = 100 * F                                         # pretrain_iter_number 100 (config_flow_100.json:36)
+    ys = torch.empty((steps, 10000), dtype=torch.int64); xs = torch.empty((steps, 10000), dtype=torch.int64)
+    for s in range(steps):                                  # the global generator continues where the init left it
+        ys[s] = torch.randint(resy, (10000, 1)).view(-1)
+        xs[s] = torch.randint(resx, (10000, 1)).view(-1)
+    af.pre_train_mapping(100, ys.numpy(), xs.numpy())
+    del ys, xs
+    p_pre, _ = af.psnr()
+    stops = sorted({i for i in rec["psnr_at"] if i <= upto} | {upto})
+    losses, p_at, done = [], {}, 0
+    for stop in stops:
+        if stop > done:
+            inds = torch.stack([torch.randint(P, (N, 1)).view(-1) for _ in range(stop - done)])
+            losses.append(af.train_steps(done, stop - done, inds.numpy()))
+            done = stop
+        if stop in rec["psnr_at"]:
+            p_at[stop] = af.psnr()[0]
+    p_end = af.psnr()[0] if upto == rec["iters"] else None
+    af.close()
+    return p_pre, p_at, p_end, np.concatenate(losses)
+
+
+@pytest.mark.skipif(not _records(), reason="no configs[1] reference record yet (tests/golden/c2_reference.npz or c2_partial_seed*.npz)")
+def test_configs1_full_schedule_against_the_reference_modules():
+    recs = _records()
+    seeds = sorted(recs)
+    d_pre, d_mid, d_end, sig = [], [], [], []
+    for seed in seeds:
+        rec = recs[seed]
+        every, n_logged = rec["every"], len(rec["curve"])
+        complete = rec["psnr_end"] is not None
+        upto = rec["iters"] if complete else (n_logged - 1) * every + 1         # a partial record: as far as its curve goes
+        video = _video(seed, rec)
+        runs = [_run(seed, rec, part, upto, video) for part in PARTITIONS]
+        del video
+        p_pre = np.array([r[0] for r in runs])
+        print("seed %d (%s flow, %s, reference CPU time %.0f s pre-train + %.0f s loop): PSNR after the pre-train hip %s / reference %.4f dB"
+              % (seed, rec["flow"], "complete" if complete else "partial: %d of %d iterations" % (upto, rec["iters"]), rec["cpu_seconds"][0], rec["cpu_seconds"][1],
+                 np.array2string(p_pre, precision=4), rec["psnr_pre"]))
+        # 8000 pre-train steps on the same draws: the pre-train loss has ONE minimum (uv = 0.8 xy), both sides orbit it
+        assert np.all(np.abs(p_pre - rec["psnr_pre"]) < 0.1), (p_pre, rec["psnr_pre"])
+        d_pre.append(float(p_pre.mean() - rec["psnr_pre"]))
+        curve = np.stack([r[3][::every][:n_logged, :6] for r in runs])          # (partition, logged iteration, term)
+        ref = rec["curve"][:curve.shape[1]]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(ref != 0, np.abs(curve / ref - 1.0), 0.0)
+        own = np.abs(curve / curve.mean(axis=0, keepdims=True) - 1.0).max(axis=0)      # this path against itself over the partitions
+        print("   total loss every %d iterations, reference:        %s" % (every, np.array2string(ref[:, 5], precision=1, max_line_width=600)))
+        for part, c in zip(PARTITIONS, curve):
+            print("   total loss every %d iterations, hip %-19s %s" % (every, (part or "shipped partition") + ":", np.array2string(c[:, 5], precision=1, max_line_width=600)))
+        print("   distance from the reference, worst term per logged iteration (best partition): %s" % np.array2string(rel.max(axis=2).min(axis=0), precision=3, max_line_width=600))
+        print("   this path against itself over the partitions, worst term per logged iteration:  %s" % np.array2string(own.max(axis=1), precision=3, max_line_width=600))
+        # iteration 0: the same batch on a state 8000 chaotic steps old (test_gpu_c1.py: 6 % on this side from one ulp of one weight)
+        assert rel[:, 0, 5].min() < 0.10, (curve[:, 0], ref[0])
+        assert np.all((ref[:, 3] > 0) == (np.arange(len(ref)) * every <= 5000)) and np.all((curve[:, :, 3] > 0) == (ref[None, :, 3] > 0))   # the switch at 5000, both sides
+        # along the curve: the total and the rgb term (what the PSNR is made of) stay within the spread the three partitions show among
+        # themselves plus 10 %, at every logged iteration including the 5000 without global rigidity
+        for t in (0, 5):
+            lim = 0.10 + 2.0 * own[:, t]
+            assert np.all(rel[:, :, t].min(axis=0) <= lim), (TERMS[t], rel[:, :, t].min(axis=0), lim)
+        for i in sorted(rec["psnr_at"]):
+            if all(i in r[1] for r in runs):
+                h = np.array([r[1][i] for r in runs])
+                print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %.4f dB" % (i, np.array2string(h, precision=4), h.mean(), rec["psnr_at"][i]))
+                d_mid.append(float(h.mean() - rec["psnr_at"][i])); sig.append(h)
+        if complete:
+            h = np.array([r[2] for r in runs])
+            print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %.4f dB" % (rec["iters"], np.array2string(h, precision=4), h.mean(), rec["psnr_end"]))
+            d_end.append(float(h.mean() - rec["psnr_end"])); sig.append(h)
+    if not sig:
+        return
+    # one run's standard deviation on this side, pooled over every (seed, evaluation) the partitions were compared at
+    sigma = float(np.sqrt(np.mean([np.var(h, ddof=1) for h in sig])))
+    npart = len(PARTITIONS)
+    tol_seed = 0.1 + 2.0 * sigma * np.sqrt(1.0 + 1.0 / npart)                   # one reference run (sigma assumed equal) against the mean of npart runs
+    print("sigma of one run on this side (pooled over partitions): %.3f dB -> per-seed tolerance %.3f dB" % (sigma, tol_seed))
+    for name, d in (("after the pre-train", d_pre), ("after 5000 iterations", d_mid), ("at the end", d_end)):
+        if not d:
+            continue
+        d = np.array(d)
+        se = float(d.std(ddof=1) / np.sqrt(len(d))) if len(d) > 1 else float("nan")
+        print("hip - reference %s: per seed %s dB ; mean %+.4f dB, standard error over seeds %.4f dB (n = %d)" % (name, np.array2string(d, precision=4), d.mean(), se, len(d)))
+        if name == "after the pre-train":
+            continue
+        assert np.all(np.abs(d) <= tol_seed), (name, d, tol_seed)
+        tol_mean = 0.1 + 2.0 * sigma * np.sqrt((1.0 + 1.0 / npart) / len(d))
+        assert abs(float(d.mean())) <= tol_mean, (name, float(d.mean()), tol_mean)

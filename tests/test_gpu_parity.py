@@ -188,6 +188,34 @@ def test_trajectory_matches_reference(case):
     assert np.abs(rec - oref).max() < 1e-4
 
 
+def test_render_matches_oracle_per_pixel(case):
+    """af_render_frame against the oracle's restatement of evaluate.py:640-661, pixel by pixel (the render was
+    pinned only transitively — forward vs IMLP, PSNR after the pre-train vs the reference): every pixel of the first, a middle and the last
+    frame within 2e-6 (tanh output scaled by 1/2: the forward bound of test_forward_matches_reference_imlp through two nets), the
+    per-frame SSE the library accumulates in fp64 against the fp64 SSE of the oracle's image, and af_psnr against the oracle's mean PSNR;
+    on the translating and on the field-flow video."""
+    from oracle import atlas_oracle as O
+    import aiod_amd
+    h, g, v = case
+    m, a = _oracle_models(g)
+    h.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict()); h.load_state_dict(aiod_amd.NET_ATLAS, a.state_dict())
+    worst = 0.0
+    for f in (0, v.F // 2, v.F - 1):
+        want = O.render_frame(m, a, v.resx, v.resy, v.F, f).numpy()
+        got, sse = h.render_frame(f)
+        assert got.shape == want.shape == (v.resy, v.resx, 3)
+        d = float(np.abs(got - want).max())
+        worst = max(worst, d)
+        assert d <= 2e-6, (f, d)
+        gt = v.video_frames[:, :, :, f].numpy().astype(np.float64)
+        sse_want = float(((want.astype(np.float64) - gt) ** 2).sum())
+        assert abs(sse - sse_want) <= 1e-5 * sse_want, (f, sse, sse_want)
+    mean_want, per_want = O.mean_psnr(m, a, v)
+    mean_got, per_got = h.psnr()
+    print("render vs oracle: worst pixel %.3g; PSNR %.6f vs %.6f dB" % (worst, mean_got, mean_want))
+    assert np.abs(per_got - np.array(per_want)).max() <= 1e-4 and abs(mean_got - mean_want) <= 1e-4
+
+
 def test_pretrain_matches_reference(af, golden):
     import aiod_amd
     m, a = _oracle_models(golden, start=False)

@@ -169,6 +169,31 @@ def test_trajectory_psnr_and_parameters_match_reference(case):
     assert rgb.shape == (int(golden_seg["resy"]), int(golden_seg["resx"]), 3) and np.isfinite(rgb).all() and sse > 0
 
 
+def test_render_matches_oracle_per_pixel(case):
+    """The alpha-blended render (evaluate.py:302-337: rgb = rgb_fg*alpha + rgb_bg*(1-alpha), foreground quadrant uv*0.5+0.5, background
+    uv*0.5-0.5) against the oracle's restatement, pixel by pixel, on both small videos: <= 2e-6, and af_psnr against the oracle's."""
+    from oracle import atlas_oracle as O
+    from conftest import seg_start_models
+    h, g, v = case
+    models = seg_start_models(g)
+    _load(h, models)
+    m1, m2, atlas, alpha = models
+    worst = 0.0
+    for f in (0, v.F // 2, v.F - 1):
+        want = O.render_frame_seg(m1, m2, atlas, alpha, v.resx, v.resy, v.F, f).numpy()
+        got, sse = h.render_frame(f)
+        d = float(np.abs(got - want).max())
+        worst = max(worst, d)
+        assert d <= 2e-6, (f, d)
+        gt = v.video_frames[:, :, :, f].numpy().astype(np.float64)
+        sse_want = float(((want.astype(np.float64) - gt) ** 2).sum())
+        assert abs(sse - sse_want) <= 1e-5 * sse_want, (f, sse, sse_want)
+    mean_want, per_want = O.mean_psnr_seg(m1, m2, atlas, alpha, v)
+    mean_got, per_got = h.psnr()
+    print("two-layer render vs oracle: worst pixel %.3g; PSNR %.6f vs %.6f dB" % (worst, mean_got, mean_want))
+    assert np.abs(per_got - np.array(per_want)).max() <= 1e-4 and abs(mean_got - mean_want) <= 1e-4
+
+
 def test_pretrained_regime_matches_oracle(af, golden_seg, small_seg_video):
     """pre_train_mapping on both mapping nets on the device (stage1_neural_atlas_seg.py:173-179), then one loop
     step compared with the oracle started from the SAME (downloaded) parameters."""

@@ -29,9 +29,11 @@ if two:
 del frames, flows, flows_rev; torch.cuda.empty_cache()
 script = os.path.join(ROOT, "all-in-one-deflicker_amd", "stage1_seg.py" if two else "stage1.py")
 t0 = time.perf_counter()
-r = subprocess.run([sys.executable, script, "--vid_name", "clip", "--root", os.path.join(d, "data"), "--down", "1", "--seed", "1"], cwd=d, capture_output=True, text=True)
+r = subprocess.run([sys.executable, script, "--vid_name", "clip", "--root", os.path.join(d, "data"), "--down", "1", "--seed", "1"], cwd=d, capture_output=True, text=True,
+                   env=dict(os.environ, AF_CLI_TIMING="1"))
 dt = time.perf_counter() - t0
+stages = [json.loads(l.split(" ", 1)[1]) for l in r.stderr.splitlines() if l.startswith("AF_CLI_TIMING ")]
 res = os.path.join(d, "results", "clip", "stage_1")
 psnr = [n for n in os.listdir(os.path.join(res, "010000")) if n.startswith("PSNR_")] if r.returncode == 0 else []
 print(json.dumps({"cli": os.path.basename(script), "returncode": r.returncode, "wall_s": dt, "outputs": len(os.listdir(os.path.join(res, "output"))) if r.returncode == 0 else 0,
-                  "psnr_marker": psnr, "stderr_tail": r.stderr[-300:] if r.returncode else ""}))
+                  "psnr_marker": psnr, "stage_seconds_inside_main": stages[0] if stages else None, "interpreter_start_and_imports_s": (dt - sum(stages[0].values())) if stages else None, "stderr_tail": r.stderr[-300:] if r.returncode else ""}))
