@@ -57,6 +57,12 @@ struct NetDesc {
   int in_feat[AF_MAX_LAYERS], out_feat[AF_MAX_LAYERS];
   size_t w_off[AF_MAX_LAYERS], b_off[AF_MAX_LAYERS];   // within the net's flat params
   size_t nparams = 0, p_base = 0;                       // p_base: offset in the global flat buffer
+  // Hidden width of the net as configured (number_of_channels_*).  The chains, tiles and split-K jobs are built around AF_HID = 256 units;
+  // a narrower net runs EXACTLY inside them: units hid..255 carry zero weights and biases, so they output relu(0) = 0, receive the gradient
+  // W^T dZ = 0, produce dW rows / columns of exact zeros, and Adam moves a zero-gradient, zero-moment parameter by lr * 0 / (0 + eps) = 0 —
+  // they stay zero for ever.  Only the ABI's flat parameter order differs: lmap[i] = physical index of logical parameter i (state_dict
+  // order of the hid-wide IMLP, implicit_neural_networks.py:43-51); empty when hid == AF_HID.
+  int hid = AF_HID; size_t nlogical = 0; std::vector<uint32_t> lmap;
   // images (float offsets into the global image buffers)
   size_t f_off[AF_MAX_LAYERS]; int f_mpad[AF_MAX_LAYERS], f_groups[AF_MAX_LAYERS];
   long long b_off_img[AF_MAX_LAYERS]; int b_mpad[AF_MAX_LAYERS];
@@ -143,7 +149,7 @@ enum { T_PREP = 0, T_FWD_1 = 1, T_FWD_2 = 2, T_LOSS = 3, T_BWD_1 = 4, T_BWD_2 = 
 
 template <class T> hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
-void describe_net(NetDesc& n, int id, int NL, int in_kind, int pe_freqs, int out, unsigned skip, bool dx0) {
+void describe_net(NetDesc& n, int id, int NL, int in_kind, int pe_freqs, int out, unsigned skip, bool dx0, int hid = AF_HID) {
   n.id = id; n.kern = (in_kind == AF_IN_PE3 && out == 2) ? AF_KIND_MAP_PE : id; n.NL = NL; n.in_kind = in_kind; n.out = out; n.skip = skip; n.dx0 = dx0; n.used = true;
   const int in_dim = in_kind == AF_IN_PE2 ? 2 : 3;
   n.pe_feats = in_kind == AF_IN_XYT ? 0 : 2 * in_dim * pe_freqs;
@@ -157,6 +163,22 @@ void describe_net(NetDesc& n, int id, int NL, int in_kind, int pe_freqs, int out
     n.b_off[l] = off; off += n.out_feat[l];
   }
   n.nparams = off;
+  n.hid = hid; n.nlogical = off; n.lmap.clear();
+  if (hid != AF_HID) {      // logical (hid-wide) state_dict order -> physical (AF_HID-wide) index
+    for (int l = 0; l < NL; ++l) {
+      const int pin = n.in_feat[l], pout = n.out_feat[l];
+      const int lout = l == NL - 1 ? out : hid;
+      const int extra = l == 0 ? n.in_feat0 : (pin - AF_HID);                 // layer 0: every input column; later: the skip-concat's PE columns behind the hidden ones
+      const int lhid = l == 0 ? 0 : hid;
+      for (int r = 0; r < lout; ++r) {
+        for (int c = 0; c < lhid; ++c) n.lmap.push_back((uint32_t)(n.w_off[l] + (size_t)r * pin + c));
+        for (int c = 0; c < extra; ++c) n.lmap.push_back((uint32_t)(n.w_off[l] + (size_t)r * pin + (l == 0 ? 0 : AF_HID) + c));
+      }
+      (void)pout;
+      for (int r = 0; r < lout; ++r) n.lmap.push_back((uint32_t)(n.b_off[l] + r));
+    }
+    n.nlogical = n.lmap.size();
+  }
 }
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -773,7 +795,8 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   auto bad = [&](const char* m) { g_create_error = std::string("af_create: ") + m; return (int)AF_EINVAL; };
   if (cfg->resx <= 1 || cfg->resy <= 1 || cfg->number_of_frames <= 0) return bad("resx/resy/number_of_frames");
   if (cfg->samples_batch <= 0) return bad("samples_batch");
-  if (cfg->number_of_channels_mapping1 != AF_HID || cfg->number_of_channels_atlas != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:19,24)");
+  auto width_ok = [](int w) { return w >= 1 && w <= AF_HID; };       // narrower nets run zero-padded inside the 256-wide chains (NetDesc::hid); wider ones are not built
+  if (!width_ok(cfg->number_of_channels_mapping1) || !width_ok(cfg->number_of_channels_atlas)) return bad("number_of_channels_mapping1 / number_of_channels_atlas must be 1..256 (config_flow_100.json:19,24)");
   auto layers_ok = [](int n) { return n >= 2 && n <= AF_MAX_LAYERS; };
   if (!layers_ok(cfg->number_of_layers_mapping1) || !layers_ok(cfg->number_of_layers_atlas)) return bad("number_of_layers_mapping1 / number_of_layers_atlas must be 2..8");
   if (cfg->positional_encoding_num_atlas < 1 || cfg->positional_encoding_num_atlas > 10) return bad("positional_encoding_num_atlas must be 1..10");
@@ -782,7 +805,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   if (cfg->derivative_amount <= 0 || cfg->global_rigidity_derivative_amount_fg <= 0) return bad("derivative amounts");
   const bool seg = cfg->two_layer != 0;
   if (seg) {
-    if (cfg->number_of_channels_mapping2 != AF_HID || cfg->number_of_channels_alpha != AF_HID) return bad("only 256 hidden channels are built (config_flow_100.json:21,26)");
+    if (!width_ok(cfg->number_of_channels_mapping2) || !width_ok(cfg->number_of_channels_alpha)) return bad("number_of_channels_mapping2 / number_of_channels_alpha must be 1..256 (config_flow_100.json:21,26)");
     if (!layers_ok(cfg->number_of_layers_mapping2) || !layers_ok(cfg->number_of_layers_alpha)) return bad("number_of_layers_mapping2 / number_of_layers_alpha must be 2..8");
     if (cfg->positional_encoding_num_alpha < 1 || cfg->positional_encoding_num_alpha > 5) return bad("positional_encoding_num_alpha must be 1..5");
     if (cfg->use_positional_encoding_mapping2 && !pe_ok(cfg->number_of_positional_encoding_mapping2)) return bad("number_of_positional_encoding_mapping2 must be 1..5 when use_positional_encoding_mapping2 is set");
@@ -808,17 +831,22 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   const int nl_atlas = cfg->number_of_layers_atlas;
   const unsigned atlas_skip = (nl_atlas > 4 ? (1u << 4) : 0u) | (nl_atlas > 7 ? (1u << 7) : 0u);
   // a mapping net with positional encoding (IMLP(use_positional=True, positional_dim=K), implicit_neural_networks.py:9-13,28-33): PE 3 -> 6K
-  if (cfg->use_positional_encoding_mapping1) describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_PE3, cfg->number_of_positional_encoding_mapping1, 2, 0u, false);
-  else describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false);
-  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, cfg->positional_encoding_num_atlas, 3, atlas_skip, true);
+  if (cfg->use_positional_encoding_mapping1) describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_PE3, cfg->number_of_positional_encoding_mapping1, 2, 0u, false, cfg->number_of_channels_mapping1);
+  else describe_net(h->nets[AF_NET_MAP1], AF_NET_MAP1, cfg->number_of_layers_mapping1, AF_IN_XYT, 0, 2, 0u, false, cfg->number_of_channels_mapping1);
+  describe_net(h->nets[AF_NET_ATLAS], AF_NET_ATLAS, nl_atlas, AF_IN_PE2, cfg->positional_encoding_num_atlas, 3, atlas_skip, true, cfg->number_of_channels_atlas);
   if (seg) {
-    if (cfg->use_positional_encoding_mapping2) describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_PE3, cfg->number_of_positional_encoding_mapping2, 2, 0u, false);
-    else describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false);
-    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, cfg->positional_encoding_num_alpha, 1, 0u, false);
+    if (cfg->use_positional_encoding_mapping2) describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_PE3, cfg->number_of_positional_encoding_mapping2, 2, 0u, false, cfg->number_of_channels_mapping2);
+    else describe_net(h->nets[AF_NET_MAP2], AF_NET_MAP2, cfg->number_of_layers_mapping2, AF_IN_XYT, 0, 2, 0u, false, cfg->number_of_channels_mapping2);
+    describe_net(h->nets[AF_NET_ALPHA], AF_NET_ALPHA, cfg->number_of_layers_alpha, AF_IN_PE3, cfg->positional_encoding_num_alpha, 1, 0u, false, cfg->number_of_channels_alpha);
   }
   for (NetDesc& n : h->nets) if (n.used) {
-    double f = 0, d = n.dx0 ? (double)n.in_feat0 * AF_HID : 0.0;
-    for (int l = 0; l < n.NL; ++l) { f += (double)n.in_feat[l] * n.out_feat[l]; if (l >= 1) d += (double)AF_HID * n.out_feat[l]; }
+    // ALGORITHMIC work = what the configured (hid-wide) net needs, not what the 256-wide machinery executes for a narrower one
+    auto lw = [&](int w) { return w == AF_HID ? n.hid : (w > AF_HID ? w - AF_HID + n.hid : w); };     // physical width -> logical (hidden part narrowed, PE columns kept)
+    double f = 0, d = n.dx0 ? (double)n.in_feat0 * n.hid : 0.0;
+    for (int l = 0; l < n.NL; ++l) {
+      const double lin = l == 0 ? n.in_feat0 : lw(n.in_feat[l]), lout = l == n.NL - 1 ? n.out : n.hid;
+      f += lin * lout; if (l >= 1) d += (double)n.hid * lout;
+    }
     h->flop_fwd[n.id] = 2.0 * f; h->flop_dx[n.id] = 2.0 * d;
   }
   size_t fc = 0, bc = 0, biasc = 0, pc = 0;
@@ -954,13 +982,29 @@ int af_upload_video(af_handle* h, const float* frames, const float* flow_fwd, co
 
 size_t af_param_count(const af_handle* h, int net) {
   if (!h || net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return 0;
-  return h->nets[net].nparams;
+  return h->nets[net].nlogical;
 }
 
 static int check_net(af_handle* h, int net, size_t n) {
   if (!h) return AF_EINVAL;
   if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
-  if (n != h->nets[net].nparams) return h->fail(AF_EINVAL, "parameter count mismatch");
+  if (n != h->nets[net].nlogical) return h->fail(AF_EINVAL, "parameter count mismatch");
+  return AF_OK;
+}
+// The ABI's flat order <-> the device buffers (params, Adam moments, gradients): a straight copy for a 256-wide net, a scatter into /
+// gather out of the zero-padded physical layout for a narrower one (NetDesc::lmap).  put zeroes the padding: it must BE zero (see NetDesc::hid).
+static int put_flat(af_handle* h, const NetDesc& n, float* dev, const float* flat) {
+  if (n.lmap.empty()) { HCHK(hipMemcpy(dev + n.p_base, flat, n.nparams * 4, hipMemcpyHostToDevice)); return AF_OK; }
+  std::vector<float> phys(n.nparams, 0.f);
+  for (size_t i = 0; i < n.nlogical; ++i) phys[n.lmap[i]] = flat[i];
+  HCHK(hipMemcpy(dev + n.p_base, phys.data(), n.nparams * 4, hipMemcpyHostToDevice));
+  return AF_OK;
+}
+static int get_flat(af_handle* h, const NetDesc& n, const float* dev, float* flat) {
+  if (n.lmap.empty()) { HCHK(hipMemcpy(flat, dev + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost)); return AF_OK; }
+  std::vector<float> phys(n.nparams);
+  HCHK(hipMemcpy(phys.data(), dev + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n.nlogical; ++i) flat[i] = phys[n.lmap[i]];
   return AF_OK;
 }
 
@@ -969,7 +1013,7 @@ int af_set_params(af_handle* h, int net, const float* flat, size_t n) {
   if (!flat) return h->fail(AF_EINVAL, "af_set_params: null");
   HCHK(hipSetDevice(h->device));
   HCHK(hipStreamSynchronize(h->stream));
-  HCHK(hipMemcpy(h->params + h->nets[net].p_base, flat, n * 4, hipMemcpyHostToDevice));
+  rc = put_flat(h, h->nets[net], h->params, flat); if (rc) return rc;
   rc = repack(h, h->sched[0]); if (rc) return rc;
   HCHK(hipStreamSynchronize(h->stream));
   std::fill(h->frame_sse_valid.begin(), h->frame_sse_valid.end(), 0);
@@ -980,8 +1024,7 @@ int af_get_params(af_handle* h, int net, float* flat, size_t n) {
   int rc = check_net(h, net, n); if (rc) return rc;
   if (!flat) return h->fail(AF_EINVAL, "af_get_params: null");
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
-  HCHK(hipMemcpy(flat, h->params + h->nets[net].p_base, n * 4, hipMemcpyDeviceToHost));
-  return AF_OK;
+  return get_flat(h, h->nets[net], h->params, flat);
 }
 
 int af_get_adam_state(af_handle* h, int net, float* m, float* v, int64_t* step) {
@@ -989,8 +1032,9 @@ int af_get_adam_state(af_handle* h, int net, float* m, float* v, int64_t* step) 
   if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
   const NetDesc& n = h->nets[net];
-  if (m) HCHK(hipMemcpy(m, h->adam_m + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost));
-  if (v) HCHK(hipMemcpy(v, h->adam_v + n.p_base, n.nparams * 4, hipMemcpyDeviceToHost));
+  int rc = AF_OK;
+  if (m && (rc = get_flat(h, n, h->adam_m, m)) != AF_OK) return rc;
+  if (v && (rc = get_flat(h, n, h->adam_v, v)) != AF_OK) return rc;
   if (step) *step = h->adam_step;
   return AF_OK;
 }
@@ -1001,8 +1045,9 @@ int af_set_adam_state(af_handle* h, int net, const float* m, const float* v, int
   if (step < 0) return h->fail(AF_EINVAL, "negative step");
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
   const NetDesc& n = h->nets[net];
-  if (m) HCHK(hipMemcpy(h->adam_m + n.p_base, m, n.nparams * 4, hipMemcpyHostToDevice));
-  if (v) HCHK(hipMemcpy(h->adam_v + n.p_base, v, n.nparams * 4, hipMemcpyHostToDevice));
+  int rc = AF_OK;
+  if (m && (rc = put_flat(h, n, h->adam_m, m)) != AF_OK) return rc;
+  if (v && (rc = put_flat(h, n, h->adam_v, v)) != AF_OK) return rc;
   h->adam_step = step;
   return AF_OK;
 }
@@ -1080,8 +1125,7 @@ int af_get_timing(af_handle* h, double* ms16, int64_t* counts16, double* flops16
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n) {
   int rc = check_net(h, net, n); if (rc) return rc;
   HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
-  HCHK(hipMemcpy(flat, h->grads + h->nets[net].p_base, n * 4, hipMemcpyDeviceToHost));
-  return AF_OK;
+  return get_flat(h, h->nets[net], h->grads, flat);
 }
 
 int af_loss_width(const af_handle* h) { return h && h->seg ? 16 : 8; }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
     ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
     // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
-    __builtin_amdgcn_sched_barrier(0);
+    AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } ts.template part<decltype(gi)::value>(in); };
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_bwd(BwdArgs a) {
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
     // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
-    __builtin_amdgcn_sched_barrier(0);
+    AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } ts.template part<decltype(gi)::value>(in); };

@@ -73,6 +73,11 @@ struct ChunkStream {
 // where torch.relu propagates it: a NaN pre-activation needs a non-finite parameter or input (Adam's steps are bounded by
 // lr), and k_adam raises AF_ENAN for any non-finite parameter (elem.hip), so the condition is reported, not healed silently.
 AF_DEV float af_relu(float z) { float v; asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(z)); return v; }
+#ifdef AF_NO_ELEMWISE_FENCE      // experiment: the build that corrupted two-layer nets in round 3 (tools/experiments/README.md, "element-wise fence")
+#define AF_ELEMWISE_FENCE() do { } while (0)
+#else
+#define AF_ELEMWISE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // Accumulator initialisation = bias.  The net's padded bias rows ([NL][256] floats, <= 8 KB) are copied once per
 // workgroup into LDS behind the two weight buffers: 32 ds_read_b128 per layer cost a fraction of the 32 VMEM loads

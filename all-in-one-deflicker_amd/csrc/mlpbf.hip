@@ -415,7 +415,7 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
     }
     // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
     // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
-    __builtin_amdgcn_sched_barrier(0);
+    AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
 
@@ -547,7 +547,7 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
     // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
-    __builtin_amdgcn_sched_barrier(0);
+    AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };

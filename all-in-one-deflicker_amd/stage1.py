@@ -413,7 +413,7 @@ def main(config, args, two_layer=False):
                 sd["hidden.%d.weight" % i] = w; sd["hidden.%d.bias" % i] = b
             af.load_state_dict(net, sd)
         # pre_train_mapping reads nothing of the video (unwrap_utils.py:176-198: random pixel coordinates of frame f against uv = 0.8 xy;
-        # asserted in oracle/make_golden.py), so it starts NOW, on the handle's stream from its own thread (ctypes drops the GIL), while this
+        # asserted by the fixture generators under tests/), so it starts NOW, on the handle's stream from its own thread (ctypes drops the GIL), while this
         # thread decodes, resizes and uploads the clip: 1.7 s (single) / 3.3 s (fg/bg) of the schedule leave the critical path (round 5).
         # The draws keep the reference's order: init, pre-train seed(s), sampler seed.
         jobs = []

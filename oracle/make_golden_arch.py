@@ -35,18 +35,21 @@ KINDS = {"mapping": (3, 2, False, 4, []), "atlas": (2, 3, True, 10, [4, 7]), "al
 VARIANTS = [("mapping", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("atlas", n) for n in (2, 3, 4, 5, 6, 7, 8)] + [("alpha", n) for n in (2, 3, 5, 8)] \
     + [("mappingpe1", 4), ("mappingpe2", 4), ("mappingpe3", 5), ("mappingpe4", 6), ("mappingpe4", 3), ("mappingpe5", 2)] \
     + [("atlaspe6", 8), ("atlaspe1", 5), ("alphape3", 8)]
+# round 5: hidden widths other than 256 (number_of_channels_*, implicit_neural_networks.py:20,43-51): (kind, layers, hidden_dim) -> key "<kind>_<layers>_w<width>"
+WIDTHS = [("mapping", 6, 128), ("mapping", 6, 64), ("mapping", 4, 200), ("mapping", 2, 100), ("mapping", 3, 1), ("atlas", 8, 128), ("atlas", 5, 72), ("alpha", 8, 128),
+          ("alpha", 3, 33), ("mappingpe4", 6, 128)]
 ROWS = 96
 
 
 def main():
     out = {}
-    for kind, nl in VARIANTS:
+    for kind, nl, width in [(k, n, 256) for k, n in VARIANTS] + WIDTHS:
         ind, outd, pos, pdim, skips = KINDS[kind]
-        seed = 7000 + 10 * nl + len(kind)
+        seed = 7000 + 10 * nl + len(kind) + (0 if width == 256 else 1000 + width)
         torch.manual_seed(seed)
-        ref = IMLP(input_dim=ind, output_dim=outd, hidden_dim=256, use_positional=pos, positional_dim=pdim, num_layers=nl, skip_layers=skips, verbose=False)
+        ref = IMLP(input_dim=ind, output_dim=outd, hidden_dim=width, use_positional=pos, positional_dim=pdim, num_layers=nl, skip_layers=skips, verbose=False)
         torch.manual_seed(seed)
-        ora = O.OracleIMLP(ind, outd, 256, pos, pdim, skips, nl)
+        ora = O.OracleIMLP(ind, outd, width, pos, pdim, skips, nl)
         for (kn, pr), (_, po) in zip(ref.state_dict().items(), ora.state_dict().items()):
             assert torch.equal(pr, po), (kind, nl, kn)
         g = torch.Generator().manual_seed(seed + 1)
@@ -54,7 +57,7 @@ def main():
         with torch.no_grad():
             y = ref(rows)
             assert torch.equal(y, ora(rows)), (kind, nl)
-        key = "%s_%d" % (kind, nl)
+        key = "%s_%d" % (kind, nl) + ("" if width == 256 else "_w%d" % width)
         out[key + "_seed"] = seed
         out[key + "_rows"] = rows.numpy()
         out[key + "_out"] = y.numpy()
@@ -63,7 +66,8 @@ def main():
     if os.environ.get("AF_GOLDEN_CHECK_ONLY"):
         print("arch variants: restatement == reference IMLP (check only)")
         return
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "arch_variants.npz"), variants=np.array(["%s_%d" % v for v in VARIANTS]), **out)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "arch_variants.npz"), variants=np.array(["%s_%d" % v for v in VARIANTS]),
+                        width_variants=np.array(["%s_%d_w%d" % v for v in WIDTHS]), **out)
     print("written tests/golden/arch_variants.npz")
 
 

@@ -158,6 +158,67 @@ def test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, lay
         af.close()
 
 
+@pytest.mark.parametrize("mlp_mode", [1, 0])
+def test_forward_of_narrower_nets_matches_reference_imlp(mlp_mode):
+    """number_of_channels_* below 256 (implicit_neural_networks.py:20,43-51; stage1_neural_atlas.py:69-72,115,124): the net runs zero-padded
+    inside the 256-wide chains (host.hip NetDesc::hid) and the ABI speaks the narrow net's own state_dict order.  Forward outputs of ten
+    (kind, depth, width) variants — widths 1, 33, 64, 72, 100, 128, 200; with skips, with mapping PE, the loop-free two-layer chain —
+    against the reference's IMLP of that width, and the parameter round trip through af_set_params / af_get_params."""
+    import aiod_amd
+    A = aiod_amd.atlasfit
+    g = dict(np.load(GOLDEN))
+    worst = 0.0
+    for name in [str(v) for v in g["width_variants"]]:
+        kind, nl, w = name.split("_")[0], int(name.split("_")[1]), int(name.split("_")[2][1:])
+        over = {}
+        if kind.startswith("mappingpe"):
+            nets = ((A.NET_MAPPING1, "mapping1"), (A.NET_MAPPING2, "mapping2")); width_in = 3
+            for _, which in nets:
+                over.update({"use_positional_encoding_" + which: True, "number_of_positional_encoding_" + which: int(kind[len("mappingpe"):])})
+        elif kind == "mapping":
+            nets = ((A.NET_MAPPING1, "mapping1"), (A.NET_MAPPING2, "mapping2")); width_in = 3
+        elif kind == "atlas":
+            nets = ((A.NET_ATLAS, "atlas"),); width_in = 2
+        else:
+            nets = ((A.NET_ALPHA, "alpha"),); width_in = 3
+        for net, which in nets:
+            cfg = A.default_config(64, 48, 4, dict(over, **{"number_of_layers_" + which: nl, "number_of_channels_" + which: w}), two_layer=True)
+            af = aiod_amd.AtlasFit(cfg)
+            try:
+                af.set_mlp_mode(mlp_mode)
+                assert af.param_count(net) == int(g[name + "_nparams"]), (name, af.param_count(net))
+                sd = _state_dict(int(g[name + "_seed"]), A.imlp_shapes(net, cfg))
+                af.load_state_dict(net, sd)
+                flat = np.concatenate([np.asarray(t).reshape(-1) for t in sd.values()])
+                assert np.array_equal(af.get_params_flat(net), flat), name                 # logical order in, logical order out, bit for bit
+                rows = np.zeros((g[name + "_rows"].shape[0], 4), np.float32); rows[:, :width_in] = g[name + "_rows"]
+                want = g[name + "_out"]
+                err = float(np.abs(af.debug_forward(net, rows)[:, :want.shape[1]] - want).max())
+                worst = max(worst, err)
+                assert err < 5e-6, (name, net, mlp_mode, err)
+            finally:
+                af.close()
+    print("mlp_mode %d: worst forward distance of the narrower nets from the reference IMLP: %.3g" % (mlp_mode, worst))
+
+
+@pytest.mark.parametrize("two_layer,widths", [(False, dict(number_of_channels_mapping1=128, number_of_channels_atlas=128)),
+                                              (False, dict(number_of_channels_mapping1=40, number_of_channels_atlas=200, number_of_layers_mapping1=2)),
+                                              (True, dict(number_of_channels_mapping1=64, number_of_channels_mapping2=200, number_of_channels_atlas=128, number_of_channels_alpha=96))])
+def test_training_steps_of_narrower_nets_match_oracle(two_layer, widths, golden, golden_seg, small_video, small_seg_video):
+    """The whole loop on narrower nets: pre-train losses, three Adam steps (every loss term within 1e-3 of the CPU oracle built with the same
+    widths), end weights and Adam moments close — which they can only be if the padding units stay exactly zero through forward, backward,
+    the weight-gradient GEMM and Adam."""
+    test_training_steps_of_non_shipped_architectures_match_oracle(two_layer, widths, golden, golden_seg, small_video, small_seg_video)
+
+
+def test_widths_outside_1_to_256_are_rejected():
+    import aiod_amd
+    A = aiod_amd.atlasfit
+    for key, bad in (("number_of_channels_mapping1", 257), ("number_of_channels_atlas", 0), ("number_of_channels_alpha", 512), ("number_of_channels_mapping2", -3)):
+        with pytest.raises(aiod_amd.AtlasFitError):
+            aiod_amd.AtlasFit(A.default_config(64, 48, 4, {key: bad}, two_layer=True))
+
+
 def test_layer_counts_outside_2_to_8_are_rejected():
     import aiod_amd
     A = aiod_amd.atlasfit

@@ -191,7 +191,7 @@ def test_trajectory_matches_reference(case):
 def test_render_matches_oracle_per_pixel(case):
     """af_render_frame against the oracle's restatement of evaluate.py:640-661, pixel by pixel (the render was
     pinned only transitively — forward vs IMLP, PSNR after the pre-train vs the reference): every pixel of the first, a middle and the last
-    frame within 2e-6 (tanh output scaled by 1/2: the forward bound of test_forward_matches_reference_imlp through two nets), the
+    frame no further from an fp64 twin of the oracle than twice what the oracle's own fp32 render is (floor 2e-6), the
     per-frame SSE the library accumulates in fp64 against the fp64 SSE of the oracle's image, and af_psnr against the oracle's mean PSNR;
     on the translating and on the field-flow video."""
     from oracle import atlas_oracle as O
@@ -199,14 +199,24 @@ def test_render_matches_oracle_per_pixel(case):
     h, g, v = case
     m, a = _oracle_models(g)
     h.load_state_dict(aiod_amd.NET_MAPPING1, m.state_dict()); h.load_state_dict(aiod_amd.NET_ATLAS, a.state_dict())
+    import copy
+    m64, a64 = copy.deepcopy(m).double(), copy.deepcopy(a).double()
+    a64.b = a64.b.double()
     worst = 0.0
     for f in (0, v.F // 2, v.F - 1):
         want = O.render_frame(m, a, v.resx, v.resy, v.F, f).numpy()
+        torch.set_default_dtype(torch.float64)          # the oracle's coordinate grid follows the default dtype
+        try:
+            want64 = O.render_frame(m64, a64, v.resx, v.resy, v.F, f).numpy()
+        finally:
+            torch.set_default_dtype(torch.float32)
         got, sse = h.render_frame(f)
         assert got.shape == want.shape == (v.resy, v.resx, 3)
-        d = float(np.abs(got - want).max())
+        d, e_ref, e_hip = float(np.abs(got - want).max()), float(np.abs(want - want64).max()), float(np.abs(got - want64).max())
         worst = max(worst, d)
-        assert d <= 2e-6, (f, d)
+        # the mapping net's last-ulp round-off reaches the atlas through Fourier features up to 2^9 pi (x800 in phase): two fp32
+        # implementations differ by what either differs from exact arithmetic, so THAT is the yardstick, measured per frame
+        assert e_hip <= max(2e-6, 2.0 * e_ref) and d <= 2e-6 + 2.0 * e_ref, (f, d, e_hip, e_ref)
         gt = v.video_frames[:, :, :, f].numpy().astype(np.float64)
         sse_want = float(((want.astype(np.float64) - gt) ** 2).sum())
         assert abs(sse - sse_want) <= 1e-5 * sse_want, (f, sse, sse_want)
