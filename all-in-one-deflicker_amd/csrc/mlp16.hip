@@ -147,8 +147,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_fwd(FwdArgs a) {
       }
     if (live) { uint2 m2 = make_uint2(mk[0], mk[1]); *(uint2*)(a.masks + (((size_t)l * a.nt_stride * 2 + t16) * 64 + lane) * 2) = m2; }
     ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
-    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
-    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): gfx950 needs TWO wait states between a VALU write of a VGPR and an MFMA
+    // reading it as SrcA / SrcB (tools/hazardprobe.hip); hipcc pads its own VALU ops and cannot see these.  Left to the scheduler they sink to just in
+    // front of the output layer's MFMAs (a two-layer net has nothing else behind them): stale operands, a corrupted chain.  isa_check.py rule (d)
+    // proves on every build that no such pair exists
     AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } };
@@ -240,8 +242,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp16_bwd(BwdArgs a) {
         in[T * 4 + r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)acc[T][r]) &
                                                   (uint32_t)__builtin_amdgcn_sbfe((int)mk[T >> 3], 31 - ((T & 7) * 4 + r), 1));
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
-    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
-    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): gfx950 needs TWO wait states between a VALU write of a VGPR and an MFMA
+    // reading it as SrcA / SrcB (tools/hazardprobe.hip); hipcc pads its own VALU ops and cannot see these.  Left to the scheduler they sink to just in
+    // front of the output layer's MFMAs (a two-layer net has nothing else behind them): stale operands, a corrupted chain.  isa_check.py rule (d)
+    // proves on every build that no such pair exists
     AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 4) { cs.issue2(); cs.issue2(); } };

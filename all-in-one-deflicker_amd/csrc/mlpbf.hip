@@ -413,8 +413,10 @@ AF_DEV void mlp_fwd_body_bf(const FwdArgs& a, int wg, char* smem) {
       }
       ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
     }
-    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
-    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): gfx950 needs TWO wait states between a VALU write of a VGPR and an MFMA
+    // reading it as SrcA / SrcB (tools/hazardprobe.hip); hipcc pads its own VALU ops and cannot see these.  Left to the scheduler they sink to just in
+    // front of the output layer's MFMAs (a two-layer net has nothing else behind them): stale operands, a corrupted chain.  isa_check.py rule (d)
+    // proves on every build that no such pair exists
     AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
@@ -545,8 +547,10 @@ AF_DEV void mlp_bwd_body_bf(const BwdArgs& a, int wg, char* smem) {
     const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
     bf_mask_all(in, acc, mk, std::make_integer_sequence<int, 128>{});
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
-    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): hipcc's hazard handling does not look inside them, and scheduled
-    // among the LDS-DMA issues that follow they corrupted the chain of a two-layer net (a VGPR rewritten under an in-flight global_load_lds)
+    // the element-wise ops above are inline asm (af_relu / bf_mask_keep): gfx950 needs TWO wait states between a VALU write of a VGPR and an MFMA
+    // reading it as SrcA / SrcB (tools/hazardprobe.hip); hipcc pads its own VALU ops and cannot see these.  Left to the scheduler they sink to just in
+    // front of the output layer's MFMAs (a two-layer net has nothing else behind them): stale operands, a corrupted chain.  isa_check.py rule (d)
+    // proves on every build that no such pair exists
     AF_ELEMWISE_FENCE();
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };

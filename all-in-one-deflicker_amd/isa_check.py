@@ -11,7 +11,14 @@ round 3 met both.  Here the build fails instead:
                vector-memory instruction;
   dw.o     (c) the main loop of k_dw_bf<6> holds 192 MFMAs (two slotted 8x8 stages), never more than two back to back, two counted
                `s_waitcnt vmcnt(8)` + `s_barrier`, and 16 LDS-DMA pieces each directly behind its m0 write and one wait state;
-  every unit: no scratch_ instruction (build.py's remark check, restated on the disassembly).
+  every unit: no scratch_ instruction (build.py's remark check, restated on the disassembly);
+           (d) no v_mfma reads, as SrcA or SrcB, a VGPR that a VALU instruction wrote fewer than TWO wait states earlier.  gfx950 needs
+               them (measured, tools/hazardprobe.hip: with 0 or 1 wait states between `v_max_f32 vX, ...` and `v_mfma ... vX` the MFMA reads
+               the OLD content of vX in > 96 % of the lanes, with 2 never); hipcc inserts them for the VALU instructions it can see and
+               NOT behind one inside an asm statement.  The chains' element-wise ops (af_relu = one asm v_max_f32, bf_mask_keep) are such
+               writers: sunk by the scheduler to just in front of the output layer's v_mfma_f32_4x4x1 that read them, they corrupted the
+               forward of two-layer nets in round 3 (five such pairs in today's build with -DAF_NO_ELEMWISE_FENCE, none in the shipped one).
+               AF_ELEMWISE_FENCE() (a sched_barrier behind the asm ops) keeps them apart; THIS rule is what proves it did, on every build.
 """
 import os
 import re
@@ -188,12 +195,46 @@ def check_dw_slots(name, ins):
     return max(fill[1:-1]), (sum(fill[1:-1]) / float(len(fill) - 2))
 
 
+def check_valu_write_to_mfma_read(name, ins, need=2):
+    """(d) every v_mfma: its SrcA / SrcB VGPRs were not written by a VALU instruction within the last `need` wait states (s_nop N = N + 1
+    wait states, any other instruction 1).  Scanned linearly over the kernel: a pair across a branch target can only make it stricter."""
+    n = 0
+    for i, s in enumerate(ins):
+        if not s.startswith("v_mfma"):
+            continue
+        ops = [t.strip() for t in s.split(None, 1)[1].split(",")]
+        srcs = set()
+        for t in ops[1:3]:
+            kind, regs = _regs(t.split()[0])
+            if kind == "v":
+                srcs |= regs
+        n += 1
+        ws, j = 0, i - 1
+        while j >= 0 and ws < need and srcs:
+            t = ins[j]
+            op = t.split()[0]
+            if op == "s_nop":
+                ws += int(t.split()[1], 0) + 1
+            else:
+                if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_readlane", "v_readfirstlane")):
+                    kind, regs = _regs(t.split(None, 1)[1].split(",")[0].strip()) if len(t.split(None, 1)) > 1 else (None, set())
+                    if kind == "v" and regs & srcs:
+                        raise RuntimeError("%s: %r reads v%d written by %r only %d wait state(s) earlier (gfx950 needs %d between a VALU write and an MFMA "
+                                           "SrcA/SrcB read; an asm VALU op scheduled next to its MFMA consumer?)" % (name, s, min(regs & srcs), t, ws, need))
+                ws += 1
+            j -= 1
+    return n
+
+
 def check_unit(unit, obj, verbose=True):
     ks = disassemble(obj)
     for name, ins in ks.items():
         if any(s.startswith("scratch_") for s in ins):
             raise RuntimeError("%s: %s uses scratch memory" % (unit, name))
     msg = []
+    nm = sum(check_valu_write_to_mfma_read(n, i) for n, i in ks.items())
+    if nm:
+        msg.append("%d MFMAs, none reads a VGPR a VALU op wrote < 2 wait states earlier" % nm)
     if unit == "mlpbf.hip":
         na = sum(check_agpr_fragment_reads(n, i) for n, i in ks.items())
         nb = sum(check_counted_publish(n, i) for n, i in ks.items())

@@ -31,6 +31,39 @@ def test_fragment_read_without_wait_is_caught():
     assert m.check_agpr_fragment_reads("k", [ok[0], "v_mfma_f32_32x32x16_bf16 a[16:31], a[4:7], v[8:11], a[16:31]", ok[2], ok[3]]) == 1
 
 
+def test_valu_write_next_to_its_mfma_reader_is_caught():
+    """Rule (d), the pair behind round 3's corrupted two-layer chains: gfx950 needs two wait states between a VALU write of a VGPR and an MFMA
+    reading it as SrcA / SrcB (tools/hazardprobe.hip on the MI355X: 0 or 1 wait states -> the OLD register content in > 96 % of the lanes,
+    2 -> never).  hipcc pads its own VALU instructions and cannot see one inside an asm statement: the instruction streams below are the
+    shapes the unfenced build (-DAF_NO_ELEMWISE_FENCE) produced and the shapes that are safe."""
+    m = _mod()
+    relu, mfma = "v_max_f32_e32 v10, 0, v2", "v_mfma_f32_4x4x1_16b_f32 a[0:3], v9, v10, a[0:3]"
+    with pytest.raises(RuntimeError, match="only 0 wait state"):
+        m.check_valu_write_to_mfma_read("k", [relu, mfma])
+    with pytest.raises(RuntimeError, match="only 1 wait state"):                           # the five pairs of the unfenced mlpbf.o: one instruction in between
+        m.check_valu_write_to_mfma_read("k", [relu, "v_accvgpr_read_b32 v3, a17", mfma])
+    with pytest.raises(RuntimeError, match="only 1 wait state"):
+        m.check_valu_write_to_mfma_read("k", [relu, "s_nop 0", mfma])
+    with pytest.raises(RuntimeError):                                                      # SrcA as well, and a write of part of a register tuple
+        m.check_valu_write_to_mfma_read("k", ["v_cvt_pk_bf16_f32 v5, v20, v21", "s_nop 0", "v_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:11], a[0:15]"])
+    assert m.check_valu_write_to_mfma_read("k", [relu, "s_nop 1", mfma]) == 1              # two wait states: safe
+    assert m.check_valu_write_to_mfma_read("k", [relu, "v_accvgpr_read_b32 v3, a17", "v_max_f32_e32 v11, 0, v3", mfma]) == 1
+    assert m.check_valu_write_to_mfma_read("k", ["v_max_f32_e32 v12, 0, v2", mfma]) == 1   # another register
+    assert m.check_valu_write_to_mfma_read("k", ["v_accvgpr_write_b32 a9, v2", "v_mfma_f32_32x32x16_bf16 a[0:15], a[8:11], v[8:11], a[0:15]"]) == 1   # AGPR sources are another hazard class (hipcc's own instructions)
+
+
+@pytest.mark.skipif(not os.environ.get("AF_SLOW_ISA_TEST"), reason="compiles mlpbf.hip without the element-wise fence (~1 min): AF_SLOW_ISA_TEST=1")
+def test_the_unfenced_build_is_rejected(tmp_path):
+    """The real thing: mlpbf.hip compiled with -DAF_NO_ELEMWISE_FENCE puts an asm v_max_f32 one wait state in front of the v_mfma_f32_4x4x1
+    that reads it (and fails tests/test_gpu_arch.py on the MI355X: gpurun_out r5b/pytest_nofence.log); rule (d) must refuse it."""
+    import subprocess
+    m = _mod()
+    obj = str(tmp_path / "mlpbf_nofence.o")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DAF_NO_ELEMWISE_FENCE", "-c", os.path.join(PKG, "csrc", "mlpbf.hip"), "-o", obj], check=True)
+    with pytest.raises(RuntimeError, match="wait state"):
+        m.check_unit("mlpbf.hip", obj, verbose=False)
+
+
 def test_counted_publish_is_checked():
     m = _mod()
     stores = ["buffer_store_dword v%d, v1, s[4:7], 0 offen" % i for i in range(16)]
