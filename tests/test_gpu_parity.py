@@ -258,7 +258,7 @@ def test_device_sampler_runs_and_is_deterministic(af, golden):
 def test_error_paths(golden):
     import aiod_amd
     with pytest.raises(aiod_amd.AtlasFitError):
-        aiod_amd.AtlasFit(_cfg(golden, number_of_channels_atlas=128))
+        aiod_amd.AtlasFit(_cfg(golden, number_of_channels_atlas=512))      # widths above 256 are not built (1..256 run zero-padded since round 5)
     h = aiod_amd.AtlasFit(_cfg(golden))
     with pytest.raises(aiod_amd.AtlasFitError):
         h.train_steps(0, 1)                            # no video uploaded
