@@ -121,6 +121,7 @@ def main(path):
     v = O.synthetic_video(768, 432, 80, seed=0, flow="field")
     rng = np.random.default_rng(0)
     S = 3000
+    res = {}
     for tag, it in (("it0", 0), ("it5000", 5000), ("it10001", 10001)):
         m, a = O.build_single_atlas_models(cfg, seed=0)
         for mdl, key in ((m, tag + "_net%d" % aiod_amd.NET_MAPPING1), (a, tag + "_net%d" % aiod_amd.NET_ATLAS)):
@@ -143,7 +144,6 @@ def main(path):
         tr.loss_and_grads(min(it, 10000), inds)
         for h in hooks:
             h.remove()
-        res = {}
         for (nm, li), c in sorted(caps.items()):
             X = np.concatenate(c["X"]); dZ = np.concatenate(c["dZ"][::-1])          # backward hooks fire in reverse call order
             W = dict((("mapping", m), ("atlas", a)))[nm].hidden[li].weight.detach().numpy()[:, :256]
