@@ -433,16 +433,22 @@ def main(config, args, two_layer=False):
         pre = threading.Thread(target=pretrain, name="af-pretrain")
         pre.start()
     mark("handle + init")
-    if getattr(args, "host_loader", False):      # the numpy restatement of the reference loader (slow; kept as the cross-check)
-        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
-            resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
-        mask_frames = load_mask_frames(resy, resx, video_frames.shape[3], vid_root, vid_name) if two_layer else None
-    else:
-        t = load_input_data_device(resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name,
-                                   with_masks=two_layer, device=dev_ord)
-        flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
-        mask_frames = t[5] if two_layer else None
-    assert video_frames.shape[3] == F
+    try:
+        if getattr(args, "host_loader", False):      # the numpy restatement of the reference loader (slow; kept as the cross-check)
+            flows_mask, video_frames, flows_rev_mask, flows_rev, flows = load_input_data_single(
+                resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name)
+            mask_frames = load_mask_frames(resy, resx, video_frames.shape[3], vid_root, vid_name) if two_layer else None
+        else:
+            t = load_input_data_device(resy, resx, config["maximum_number_of_frames"], data_folder, True, vid_root, vid_name,
+                                       with_masks=two_layer, device=dev_ord)
+            flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
+            mask_frames = t[5] if two_layer else None
+        assert video_frames.shape[3] == F
+    except BaseException:       # a missing flow / mask file: the pre-train thread still owns the handle — let it finish before the handle goes away
+        if pre is not None:
+            pre.join()
+        af.close()
+        raise
     mark("input builder")
     if pre is not None:
         pre.join()

@@ -87,6 +87,28 @@ def test_cli_results_tree_checkpoint_and_resume(tmp_path, small_video, golden, m
     af.close()
 
 
+@pytest.mark.gpu
+def test_cli_with_a_missing_flow_file_fails_cleanly(tmp_path, small_video, monkeypatch):
+    """Round 5: the CLI starts pre_train_mapping on its own thread before the clip is read.  An input error in the main thread (here: one flow
+    file removed) must come out as the loader's FileNotFoundError with the pre-train thread joined and the handle closed — not as a crash of a
+    thread that lost its handle — and the process must be able to go on using the GPU."""
+    import aiod_amd
+    import aiod_amd.stage1 as S
+    v = small_video
+    _write_video(tmp_path / "data", v, "clip")
+    victim = sorted((tmp_path / "data" / "clip_flow").glob("*.npy"))[3]
+    victim.unlink()
+    cfg = dict(aiod_amd.atlasfit.REFERENCE_CONFIG)
+    cfg.update(samples_batch=256, iters_num=5, evaluate_every=4, pretrain_iter_number=20)
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match="optical flow"):
+        S._cli(["--config", str(tmp_path / "cfg.json"), "--vid_name", "clip", "--root", str(tmp_path / "data"), "--down", "1", "--seed", "5"])
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(v.resx, v.resy, v.F, cfg))      # the device is still usable
+    af.pre_train_mapping(1, seed=3)
+    af.close()
+
+
 def _write_masks(tmp, v, name):
     from PIL import Image
     d = tmp / (name + "_seg"); d.mkdir()
