@@ -28,6 +28,8 @@ enum af_net { AF_MAPPING1 = 0, AF_ATLAS = 1, AF_MAPPING2 = 2, AF_ALPHA = 3 };
 typedef struct af_config {
   int32_t resx, resy, number_of_frames;          /* stage1_neural_atlas.py:31-38,108 */
   int32_t samples_batch;                         /* config :7 */
+  /* number_of_channels_*: 1..256 (a narrower net runs exactly, zero-padded inside the 256-wide kernels; all flat parameter / Adam-state / gradient
+   * buffers of this ABI are in the CONFIGURED net's state_dict order and size); number_of_layers_*: 2..8 */
   int32_t number_of_channels_mapping1, number_of_layers_mapping1;   /* config :24-25  (256, 6) */
   int32_t number_of_channels_atlas, number_of_layers_atlas;         /* config :19-20  (256, 8) */
   int32_t positional_encoding_num_atlas;         /* config :31 (10) */
