@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # no warm-up, no pre-train: every k_dw / k_mlp_* dispatch in the trace belongs to bench.py's three passes over the same 40 iterations (20 with 9, 20 with
 # 7 row segments): the timed region, the per-kernel pass, and the pass with the opt-in three-product weight-gradient GEMM (k_dw_bf<3>, + 5 warm-up steps)
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 0 --pretrain-iters 0"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 0 --pretrain-iters 0 --settle-steps 0"      # no settle steps either (round 5): they would be 200 more 9-segment iterations in the averages
 run() {  # name, rocprof args..., -- cmd
   local name=$1; shift
   rm -rf /tmp/prof_$name
