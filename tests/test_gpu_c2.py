@@ -120,7 +120,9 @@ def test_configs1_full_schedule_against_the_reference_modules():
         ref = rec["curve"][:curve.shape[1]]
         with np.errstate(divide="ignore", invalid="ignore"):
             rel = np.where(ref != 0, np.abs(curve / ref - 1.0), 0.0)
-        own = np.abs(curve / curve.mean(axis=0, keepdims=True) - 1.0).max(axis=0)      # this path against itself over the partitions
+        cm = curve.mean(axis=0, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            own = np.where(cm != 0, np.abs(curve / cm - 1.0), 0.0).max(axis=0)          # this path against itself over the partitions (a term that is off: 0)
         print("   total loss every %d iterations, reference:        %s" % (every, np.array2string(ref[:, 5], precision=1, max_line_width=600)))
         for part, c in zip(PARTITIONS, curve):
             print("   total loss every %d iterations, hip %-19s %s" % (every, (part or "shipped partition") + ":", np.array2string(c[:, 5], precision=1, max_line_width=600)))
