@@ -5,7 +5,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libatlasfit.so")
-UNITS = ["mlp.hip", "mlpbf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
+UNITS = ["mlp.hip", "mlpbf.hip", "mlphf.hip", "mlp16.hip", "dw.hip", "elem.hip", "host.hip"]
 HEADERS = ["af_dev.h", "elem.h", "mlp_common.h", "bfsplit.h", "dw_slots.h", os.path.join("..", "..", "include", "atlasfit.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("AF_HIPCC_EXTRA", "").split()     # AF_HIPCC_EXTRA: -D switches of the kernel experiments (tools/experiments/README.md); use with --force
 

@@ -113,14 +113,17 @@ struct AdamJob {
   // the fp32 images with row padding *_mpad and reduction index k - sf_k0; 1 = 256x256 block as three bf16 images), -1 = none
   int32_t  sf_off; uint32_t sf_kind, sf_mpad, sf_k0;
   int32_t  sb_off; uint32_t sb_kind, sb_mpad;
+  // weight streams of the f16x3 chains (mlphf.hip): the same blocks in that stream's plan (fp32 blocks as above; kind 1 = 256x256 block as two fp16 images of 2^12 W)
+  int32_t  hf_off, hb_off;
 };
 struct AdamHyper { float step_size, bc2_sqrt, one_minus_b1, beta2, one_minus_b2, eps; };
-struct AdamBufs { float* params; float* m; float* v; float* img_f; float* img_b; float* bias_img; char* sf; char* sb; };
+struct AdamBufs { float* params; float* m; float* v; float* img_f; float* img_b; float* bias_img; char* sf; char* sb; char* hf; char* hb; };
 struct AdamArgs {
   const AdamJob* jobs; const float* partial;
   AdamBufs bufs; AdamHyper hy;
   float* grad_out;           // optional: reduced gradient in flat param order (tests)
   const float* loss_part; float* loss_out; int* counts; int loss_nblk;
-  int* nan_flag;             // set to 1 when a parameter is not finite, a folded loss term is NaN, or (check_counts) a flow-match set is empty
+  int* nan_flag;             // bit 0: a parameter is not finite, a folded loss term is NaN, or (check_counts) a flow-match set is empty;
+                             // bit 1: a hidden-layer weight with |w| >= 8 (the fixed 2^12 scale of the fp16 images covers |w| < 16: mlphf.hip)
   int check_counts;
 };

@@ -597,6 +597,19 @@ AF_DEV void emit_bf3(char* block, uint32_t m, uint32_t k, float p) {
   *(uint16_t*)(block + base + 2048) = lo;
 }
 
+// The same weight into a 256x256 block of an f16x3 chain stream (layout: mlphf.hip header): its two fp16 levels of 2^12 p — h = f16(2^12 p),
+// l = f16(2^12 p - h), round to nearest even, the residual exact — at byte ((s*8 + m/32)*2 + level)*1024 + (h*32 + m%32)*16 + 2 i, indices as in emit_bf3.
+AF_DEV void emit_hf2(char* block, uint32_t m, uint32_t k, float p) {
+  const uint32_t T = k >> 5, q = (k >> 3) & 3, hh = (k >> 2) & 1, pp = k & 3;
+  const uint32_t s = 2 * T + (q >> 1), i = 4 * (q & 1) + pp;
+  const float ps = p * 4096.f;
+  const _Float16 h = (_Float16)ps;
+  const _Float16 l = (_Float16)(ps - (float)h);
+  const size_t base = ((size_t)((s * 8 + (m >> 5)) * 2) * 2 + hh) * 32 * 16 + (size_t)(m & 31) * 16 + i * 2;
+  *(_Float16*)(block + base) = h;
+  *(_Float16*)(block + base + 1024) = l;
+}
+
 AF_DEV void emit_weight(const AdamJob& j, const AdamBufs& b, uint32_t o, uint32_t i, float p) {
   const uint32_t col = j.col0 + i;
   uint32_t k = col;
@@ -610,10 +623,18 @@ AF_DEV void emit_weight(const AdamJob& j, const AdamBufs& b, uint32_t o, uint32_
       if (j.sb_kind == 0) ((float*)(b.sb + j.sb_off))[af_img_index(j.sb_mpad, mrow, o)] = p;
       else                emit_bf3(b.sb + j.sb_off, mrow, o, p);
     }
+    if (b.hb && j.hb_off >= 0) {
+      if (j.sb_kind == 0) ((float*)(b.hb + j.hb_off))[af_img_index(j.sb_mpad, mrow, o)] = p;
+      else                emit_hf2(b.hb + j.hb_off, mrow, o, p);
+    }
   }
   if (b.sf && j.sf_off >= 0) {
     if (j.sf_kind == 0) ((float*)(b.sf + j.sf_off))[af_img_index(j.sf_mpad, o, k - j.sf_k0)] = p;
     else                emit_bf3(b.sf + j.sf_off, o, k, p);
+  }
+  if (b.hf && j.hf_off >= 0) {
+    if (j.sf_kind == 0) ((float*)(b.hf + j.hf_off))[af_img_index(j.sf_mpad, o, k - j.sf_k0)] = p;
+    else                emit_hf2(b.hf + j.hf_off, o, k, p);
   }
 }
 
@@ -667,7 +688,8 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     }
     // torch's relu / Linear carry a NaN or inf parameter into the loss; v_max_f32 (af_relu) would drop a NaN pre-activation
     // silently, so the condition is raised here instead (Adam's steps are bounded by lr: activations cannot overflow otherwise)
-    if (a.nan_flag && !(fabsf(p) <= 3.4028235e38f)) *a.nan_flag = 1;
+    if (a.nan_flag && !(fabsf(p) <= 3.4028235e38f)) atomicOr(a.nan_flag, 1);
+    if (a.nan_flag && a.bufs.hf && !is_bias && j.sf_kind == 1 && fabsf(p) >= 8.f) atomicOr(a.nan_flag, 2);      // the fp16 images hold 2^12 w: finite below |w| = 16
     if (is_bias) a.bufs.bias_img[j.bias_img_off + o] = p;
     else emit_weight(j, a.bufs, o, i, p);
   }
@@ -677,10 +699,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
       float s = 0.f;
       for (int b = 0; b < a.loss_nblk; ++b) s += a.loss_part[b * AF_LOSS_W + threadIdx.x];
       a.loss_out[threadIdx.x] = s;
-      if (a.nan_flag && !(s == s)) *a.nan_flag = 1;
+      if (a.nan_flag && !(s == s)) atomicOr(a.nan_flag, 1);
     } else if (threadIdx.x < AF_LOSS_W) {
       a.loss_out[threadIdx.x] = (float)a.counts[threadIdx.x - (AF_LOSS_W - 2)];
-      if (a.nan_flag && a.check_counts && a.counts[threadIdx.x - (AF_LOSS_W - 2)] == 0) *a.nan_flag = 1;     // mean over an empty set (loss_utils.py:317-320)
+      if (a.nan_flag && a.check_counts && a.counts[threadIdx.x - (AF_LOSS_W - 2)] == 0) atomicOr(a.nan_flag, 1);     // mean over an empty set (loss_utils.py:317-320)
       a.counts[threadIdx.x - (AF_LOSS_W - 2)] = 0;
     }
   }

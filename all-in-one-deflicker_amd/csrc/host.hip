@@ -29,6 +29,10 @@ int af_launch_fwd_multi_bf(MultiFwd* m, int train, hipStream_t s);
 int af_launch_bwd_multi_bf(MultiBwd* m, hipStream_t s);
 int af_mlp_bf_init();
 int af_mlp_chunk_bytes_bf(int net, int which, int nl);
+int af_launch_fwd_multi_hf(MultiFwd* m, int train, hipStream_t s);
+int af_launch_bwd_multi_hf(MultiBwd* m, hipStream_t s);
+int af_mlp_hf_init();
+int af_mlp_chunk_bytes_hf(int net, int which, int nl);
 int af_launch_dw(const DwArgs* a, int nwg, int mode, hipStream_t s);
 int af_dw_init();
 int af_launch_pack(const PackArgs* a, hipStream_t s);
@@ -72,6 +76,9 @@ struct NetDesc {
   // of its 256x256 bf16x3 block (-1: none) and of its fp32 block (layer 0 / skip columns / output layer; -1: none)
   size_t sf_base = 0, sb_base = 0;
   long long sf_hid[AF_MAX_LAYERS], sf_fp[AF_MAX_LAYERS], sb_hid[AF_MAX_LAYERS], sb_fp[AF_MAX_LAYERS];
+  // the same for the f16x3 chains (mlphf.hip): four 64 KB chunks of two fp16 images per 256x256 block
+  size_t hf_base = 0, hb_base = 0;
+  long long hf_hid[AF_MAX_LAYERS], hf_fp[AF_MAX_LAYERS], hb_hid[AF_MAX_LAYERS], hb_fp[AF_MAX_LAYERS];
   // activations
   int nt_cap = 0;
   float *coords = nullptr, *x0_tile = nullptr;         // input rows [rows_pad][4] (+ T-layout copy for the layer-0 dW of xyt nets)
@@ -97,8 +104,10 @@ struct af_handle {
   NetDesc nets[AF_MAX_NETS];
   size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0, sf_bytes = 0, sb_bytes = 0;
   char *img_sf = nullptr, *img_sb = nullptr;   // bf16x6 chain streams
+  char *img_hf = nullptr, *img_hb = nullptr; size_t hf_bytes = 0, hb_bytes = 0;   // f16x3 chain streams (mlphf.hip)
   int mlp_mode = 1;                            // MLP chains: 1 = hidden layers on the bf16 matrix pipe, fp32-faithful bf16x6 (mlpbf.hip); 0 = fp32 MFMA (mlp.hip);
-                                               // 2 = as 1 with the backward chain on three products (experiment)
+                                               // 2 = as 1 with the backward chain on three products (experiment);
+                                               // 3 = f16x3: two-term fp16 split with a scale per row, three products, both directions (mlphf.hip)
   float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *pre_m = nullptr, *pre_v = nullptr, *grads = nullptr;
   float *img_f = nullptr, *img_b = nullptr, *bias_img = nullptr;
   long long adam_step = 0;
@@ -244,6 +253,30 @@ bool plan_streams_bf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
   return cb_hid == 49152 && cb_blast == 2 * AF_HID * 16 && 2 * cb_bl0h == 32 * 2 * 64 * 16;
 }
 
+// Streams of the f16x3 chains (mlphf.hip): the fp32 blocks as above, four 64 KB chunks (two fp16 images of four k-steps) per 256x256 product.
+bool plan_streams_hf(NetDesc& n, size_t& f_cursor, size_t& b_cursor) {
+  const int peg = n.in_kind == AF_IN_PE3 ? 4 : (n.in_kind == AF_IN_PE2 ? 5 : 0);
+  const int cb_l0 = af_mlp_chunk_bytes_hf(n.kern, 0, n.NL), cb_hid = af_mlp_chunk_bytes_hf(n.kern, 1, n.NL), cb_skip = af_mlp_chunk_bytes_hf(n.kern, 2, n.NL);
+  const int cb_last = af_mlp_chunk_bytes_hf(n.kern, 3, n.NL), cb_blast = af_mlp_chunk_bytes_hf(n.kern, 4, n.NL), cb_bl0h = af_mlp_chunk_bytes_hf(n.kern, 5, n.NL);
+  for (int l = 0; l < AF_MAX_LAYERS; ++l) n.hf_hid[l] = n.hf_fp[l] = n.hb_hid[l] = n.hb_fp[l] = -1;
+  n.hf_base = f_cursor; n.hb_base = b_cursor;
+  size_t off = 0;
+  n.hf_fp[0] = (long long)off; off += cb_l0;
+  if ((size_t)cb_l0 < round_up((size_t)(n.in_kind == AF_IN_XYT ? 1 : peg) * 2 * AF_HID * 16, 4096)) return false;
+  for (int l = 1; l < n.NL - 1; ++l) {
+    n.hf_hid[l] = (long long)off; off += (size_t)4 * cb_hid;
+    if ((n.skip >> l) & 1) { n.hf_fp[l] = (long long)off; off += cb_skip; }
+  }
+  n.hf_fp[n.NL - 1] = (long long)off; off += cb_last;
+  f_cursor += off;
+  off = 0;
+  n.hb_fp[n.NL - 1] = (long long)off; off += cb_blast;
+  for (int l = n.NL - 2; l >= 1; --l) { n.hb_hid[l] = (long long)off; off += (size_t)4 * cb_hid; }
+  if (n.dx0) { n.hb_fp[0] = (long long)off; off += (size_t)2 * cb_bl0h; }
+  b_cursor += off;
+  return cb_hid == 65536 && cb_blast == 2 * AF_HID * 16 && 2 * cb_bl0h == 32 * 2 * 64 * 16;
+}
+
 // The kernels walk the weight stream with compile-time chunk sizes (mlp.hip ChunkBytes): the planned layout must
 // be exactly that sequence, contiguous.
 bool check_chunk_plan(const NetDesc& n) {
@@ -306,6 +339,9 @@ bool build_sched(af_handle* h, Sched& sc, const std::vector<NetUse>& uses) {
     if (n.b_off_img[l] < 0)      { a.sb_kind = 0; a.sb_off = -1; }
     else if (last_l || l == 0)   { a.sb_kind = 0; a.sb_off = (int32_t)(n.sb_base + n.sb_fp[l]); }
     else                         { a.sb_kind = 1; a.sb_off = (int32_t)(n.sb_base + n.sb_hid[l]); }
+    // f16x3 chain streams: the same blocks (same kinds) at that plan's offsets
+    a.hf_off = (int32_t)(n.hf_base + (a.sf_kind == 1 ? n.hf_hid[l] : n.hf_fp[l]));
+    a.hb_off = a.sb_off < 0 ? -1 : (int32_t)(n.hb_base + (a.sb_kind == 1 ? n.hb_hid[l] : n.hb_fp[l]));
     sc.ajobs.push_back(a);
   };
   for (const NetUse& u : uses) {
@@ -463,7 +499,7 @@ void free_net(NetDesc& n) {
 // the 16-row pre-train chains of mlp16.hip) walk the fp32 images
 FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, bool train, bool bf) {
   FwdArgs a{};
-  a.wimg = bf ? (const float*)(h->img_sf + n.sf_base) : h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
+  a.wimg = bf ? (h->mlp_mode == 3 ? (const float*)(h->img_hf + n.hf_base) : (const float*)(h->img_sf + n.sf_base)) : h->img_f + n.f_base; a.bias = h->bias_img + n.bias_base;
   a.in = in; a.in1 = nullptr; a.out = out; a.acts = train ? n.acts : nullptr; a.masks = train ? n.masks : nullptr; a.pe_tile = train ? n.pe_tile : nullptr;
   a.in_scale = 0.5f; a.in_shift0 = 0.5f; a.in_shift1 = -0.5f; a.split_row = 0x7fffffff;
   a.NT = NT; a.nt_stride = NT; a.nl = n.NL;
@@ -472,7 +508,7 @@ FwdArgs fwd_args(af_handle* h, NetDesc& n, const float* in, float* out, int NT, 
 
 BwdArgs bwd_args(af_handle* h, NetDesc& n, int NT, bool bf) {
   BwdArgs a{};
-  a.wimg = bf ? (const float*)(h->img_sb + n.sb_base) : h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
+  a.wimg = bf ? (h->mlp_mode == 3 ? (const float*)(h->img_hb + n.hb_base) : (const float*)(h->img_sb + n.sb_base)) : h->img_b + n.b_base; a.out = n.out_buf; a.dout = n.dout; a.masks = n.masks;
   a.dz = n.dz; a.dz_last = n.dz_last; a.pe_tile = n.pe_tile; a.din0 = nullptr; a.din1 = nullptr; a.din_scale = 0.5f;
   a.split_row = 0x7fffffff; a.nrows = 0; a.NT = NT; a.nt_stride = NT; a.nl = n.NL;
   return a;
@@ -509,7 +545,7 @@ AdamHyper adam_hyper(double lr, long long step) {
 int repack(af_handle* h, Sched& sc) {
   AdamArgs a{};
   a.jobs = sc.d_ajobs; a.partial = h->partial;
-  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb};
+  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb, h->img_hf, h->img_hb};
   a.nan_flag = h->nan_flag;
   LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 0, h->stream));
   return 0;
@@ -534,7 +570,8 @@ int launch_fwd(af_handle* h, int cls, std::initializer_list<FwdPart> parts, bool
   if (m.n == 0) return 0;
   if (h->step_stamp && train && (cls == T_FWD_1 || cls == T_FWD_2)) m.wg_stamp = h->step_stamp + (size_t)(cls == T_FWD_1 ? 0 : 1) * AF_STAMP_WG * 4;
   Timer t(h, cls, fl);
-  if (h->mlp_mode) LCHK(af_launch_fwd_multi_bf(&m, train ? 1 : 0, h->stream));
+  if (h->mlp_mode == 3) LCHK(af_launch_fwd_multi_hf(&m, train ? 1 : 0, h->stream));
+  else if (h->mlp_mode) LCHK(af_launch_fwd_multi_bf(&m, train ? 1 : 0, h->stream));
   else             LCHK(af_launch_fwd_multi(&m, train ? 1 : 0, h->stream));
   return 0;
 }
@@ -549,7 +586,8 @@ int launch_bwd(af_handle* h, int cls, std::initializer_list<BwdPart> parts) {
   if (h->step_stamp && (cls == T_BWD_1 || cls == T_BWD_2)) m.wg_stamp = h->step_stamp + (size_t)(cls == T_BWD_1 ? 2 : 3) * AF_STAMP_WG * 4;
   Timer t(h, cls, fl);
   m.nprod = h->mlp_mode == 2 ? 3 : 6;
-  if (h->mlp_mode) LCHK(af_launch_bwd_multi_bf(&m, h->stream));
+  if (h->mlp_mode == 3) LCHK(af_launch_bwd_multi_hf(&m, h->stream));
+  else if (h->mlp_mode) LCHK(af_launch_bwd_multi_bf(&m, h->stream));
   else             LCHK(af_launch_bwd_multi(&m, h->stream));
   return 0;
 }
@@ -577,7 +615,7 @@ int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, flo
     Timer t(h, T_ADAM);
     AdamArgs a{};
     a.jobs = sc.d_ajobs; a.partial = h->partial;
-    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb};
+    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb, h->img_hf, h->img_hb};
     a.hy = adam_hyper(h->cfg.lr, step);
     a.grad_out = h->debug ? h->grads : nullptr;
     a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = loss_nblk; a.nan_flag = h->nan_flag;
@@ -824,7 +862,7 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
   hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, device_ordinal));
   h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init()); CCHK((hipError_t)af_mlp_bf_init());
+  CCHK((hipError_t)af_mlp_init()); CCHK((hipError_t)af_mlp16_init()); CCHK((hipError_t)af_dw_init()); CCHK((hipError_t)af_mlp_bf_init()); CCHK((hipError_t)af_mlp_hf_init());
 
   // layer counts come from the config (stage1_neural_atlas.py:112-128, _seg.py:127-161); the atlas net's skip_layers=[4, 7] apply to the
   // layers it has (implicit_neural_networks.py:40-44: `if i in skip_layers` for i < num_layers, the output layer included)
@@ -854,11 +892,16 @@ int af_create(const af_config* cfg, int device_ordinal, af_handle** out) {
     n.p_base = pc; pc += n.nparams; plan_images(n, fc, bc, biasc);
     if (!check_chunk_plan(n)) { h->fail(AF_EINVAL, "weight-image plan does not match the kernels' chunk sequence"); return die(AF_EINVAL); }
     if (!plan_streams_bf(n, h->sf_bytes, h->sb_bytes)) { h->fail(AF_EINVAL, "bf16 stream plan does not match the kernels' chunk sizes"); return die(AF_EINVAL); }
+    if (!plan_streams_hf(n, h->hf_bytes, h->hb_bytes)) { h->fail(AF_EINVAL, "fp16 stream plan does not match the kernels' chunk sizes"); return die(AF_EINVAL); }
   }
   h->sf_bytes += 49152 + 65536; h->sb_bytes += 49152 + 65536;   // every LDS stage copies a full slot: keep the over-read in bounds
   if (h->sf_bytes >= ((size_t)1 << 31) || h->sb_bytes >= ((size_t)1 << 31)) { h->fail(AF_EINVAL, "stream images exceed 2 GB"); return die(AF_EINVAL); }
   CCHK(hipMalloc((void**)&h->img_sf, h->sf_bytes)); CCHK(hipMalloc((void**)&h->img_sb, h->sb_bytes));
   CCHK(hipMemset(h->img_sf, 0, h->sf_bytes)); CCHK(hipMemset(h->img_sb, 0, h->sb_bytes));
+  h->hf_bytes += 2 * 65536; h->hb_bytes += 2 * 65536;          // every LDS stage copies a full 64 KB slot
+  if (h->hf_bytes >= ((size_t)1 << 31) || h->hb_bytes >= ((size_t)1 << 31)) { h->fail(AF_EINVAL, "stream images exceed 2 GB"); return die(AF_EINVAL); }
+  CCHK(hipMalloc((void**)&h->img_hf, h->hf_bytes)); CCHK(hipMalloc((void**)&h->img_hb, h->hb_bytes));
+  CCHK(hipMemset(h->img_hf, 0, h->hf_bytes)); CCHK(hipMemset(h->img_hb, 0, h->hb_bytes));
   fc += AF_CHUNK_MAX / 4; bc += AF_CHUNK_MAX / 4;   // every LDS stage copies a full 64 KB buffer: keep the over-read in bounds
   h->total_params = pc; h->img_f_floats = fc; h->img_b_floats = bc; h->bias_floats = biasc;
   CCHK(dalloc(&h->params, pc)); CCHK(dalloc(&h->adam_m, pc)); CCHK(dalloc(&h->adam_v, pc));
@@ -915,7 +958,7 @@ void af_destroy(af_handle* h) {
   for (NetDesc& n : h->nets) if (n.used) free_net(n);
   for (Sched& s : h->sched) { (void)hipFree(s.d_jobs); (void)hipFree(s.d_ajobs); (void)hipFree(s.d_segs); }
   (void)hipFree(h->params); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->pre_m); (void)hipFree(h->pre_v); (void)hipFree(h->grads);
-  (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table); (void)hipFree(h->img_sf); (void)hipFree(h->img_sb);
+  (void)hipFree(h->img_f); (void)hipFree(h->img_b); (void)hipFree(h->bias_img); (void)hipFree(h->table); (void)hipFree(h->img_sf); (void)hipFree(h->img_sb); (void)hipFree(h->img_hf); (void)hipFree(h->img_hb);
   (void)hipFree(h->samples); (void)hipFree(h->loss_part); (void)hipFree(h->loss_log); (void)hipFree(h->counts); (void)hipFree(h->nan_flag); (void)hipFree(h->flow_rank); (void)hipFree(h->scan); (void)hipFree(h->live); (void)hipFree(h->nvalid);
   (void)hipFree(h->partial); (void)hipFree(h->dw_clock); (void)hipFree(h->step_stamp); (void)hipFree(h->r_coords); (void)hipFree(h->r_uv); (void)hipFree(h->r_uv2); (void)hipFree(h->r_al);
   (void)hipFree(h->r_t); (void)hipFree(h->r_rgb); (void)hipFree(h->r_sse);
@@ -1098,7 +1141,7 @@ int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost) {
 }
 int af_set_mlp_mode(af_handle* h, int mode) {
   if (!h) return AF_EINVAL;
-  if (mode < 0 || mode > 2) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA), 1 (bf16x6) or 2 (bf16x6 forward, three-product backward chain)");
+  if (mode < 0 || mode > 3) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA), 1 (bf16x6), 2 (bf16x6 forward, three-product bf16 backward chain) or 3 (f16x3: two-term fp16 split with a scale per row)");
   h->mlp_mode = mode;
   return AF_OK;
 }
@@ -1177,7 +1220,8 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
   if (d_ys) { (void)hipFree(d_ys); (void)hipFree(d_xs); }
   if (rc) return rc;
   if (e != hipSuccess) return h->fail(AF_EHIP, "af_pretrain sync", e);
-  { int dev_nan = 0; int r2 = take_nan_flag(h, dev_nan); if (r2) return r2; if (dev_nan) return h->fail(AF_ENAN, "af_pretrain: NaN loss or non-finite parameter"); }
+  { int dev_nan = 0; int r2 = take_nan_flag(h, dev_nan); if (r2) return r2; if (dev_nan & 1) return h->fail(AF_ENAN, "af_pretrain: NaN loss or non-finite parameter");
+    if ((dev_nan & 2) && h->mlp_mode == 3) return h->fail(AF_ERANGE, "af_pretrain: a hidden-layer weight reached |w| >= 8, beyond what the fp16 weight images of af_set_mlp_mode(h, 3) are scaled for; use mode 1 (bf16x6)"); }
   if (losses_out) {
     std::vector<float> tmp(steps * AF_LOSS_W);
     HCHK(hipMemcpy(tmp.data(), h->loss_log, steps * AF_LOSS_W * 4, hipMemcpyDeviceToHost));
@@ -1256,7 +1300,8 @@ int af_train_steps(af_handle* h, int first_iter, int n_iters, const int64_t* ind
     if (nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss (a batch without valid flow pixels, as in the reference, or divergence)");
   }
   // also without a loss buffer: a non-finite parameter, a NaN loss term or an empty flow-match set seen by k_adam
-  if (dev_nan) return h->fail(AF_ENAN, "af_train_steps: NaN loss or non-finite parameter (a batch without valid flow pixels, as in the reference, or divergence)");
+  if (dev_nan & 1) return h->fail(AF_ENAN, "af_train_steps: NaN loss or non-finite parameter (a batch without valid flow pixels, as in the reference, or divergence)");
+  if ((dev_nan & 2) && h->mlp_mode == 3) return h->fail(AF_ERANGE, "af_train_steps: a hidden-layer weight reached |w| >= 8, beyond what the fp16 weight images of af_set_mlp_mode(h, 3) are scaled for; use mode 1 (bf16x6)");
   return AF_OK;
 }
 

@@ -113,26 +113,38 @@ def _regs(tok):
 
 
 def check_agpr_fragment_reads(name, ins):
-    """(a) asm ds_read_b128 into AGPRs: waited for (lgkmcnt(0)) before an MFMA reads them."""
-    pending = {}                      # AGPR -> index of the read that has not been waited for
+    """(a) ds_read_b128 into AGPRs (the asm fragment reads, invisible to hipcc's s_waitcnt insertion, and the compiler's own): waited for before an
+    MFMA reads them.  lgkmcnt(0) retires everything; a COUNTED lgkmcnt(N) (hipcc's own waits in the fp32 blocks) retires all but the N youngest
+    LDS operations, which return in order - unless a scalar load is outstanding (SMEM shares the counter and returns out of order): then only
+    lgkmcnt(0) counts."""
+    queue = []                        # outstanding lgkm operations in issue order: (index, set of AGPRs written, is_smem)
     n = 0
     for i, s in enumerate(ins):
         op = s.split()[0]
-        if op == "ds_read_b128" and s.split()[1].startswith("a["):
-            _, regs = _regs(s.split()[1].rstrip(","))
-            for r in regs:
-                pending[r] = i
-            n += 1
-        elif op == "s_waitcnt" and "lgkmcnt(0)" in s:
-            pending.clear()
-        elif op.startswith("v_mfma") and pending:
+        if op.startswith("ds_"):
+            regs = set()
+            if op == "ds_read_b128" and s.split()[1].startswith("a["):
+                _, regs = _regs(s.split()[1].rstrip(","))
+                n += 1
+            queue.append((i, regs, False))
+        elif op.startswith(("s_load", "s_buffer_load")):
+            queue.append((i, set(), True))
+        elif op == "s_waitcnt" and "lgkmcnt(" in s:
+            cnt = int(re.search(r"lgkmcnt\((\d+)\)", s).group(1))
+            if cnt == 0:
+                queue = []
+            elif not any(q[2] for q in queue):
+                queue = queue[len(queue) - cnt:] if cnt < len(queue) else queue
+        elif op.startswith("v_mfma") and queue:
             toks = [t.strip().rstrip(",") for t in s.split(None, 1)[1].split(",")]
             for t in toks[1:3]:                        # srcA, srcB
                 kind, regs = _regs(t)
-                hit = [r for r in regs if kind == "a" and r in pending]
-                if hit:
-                    raise RuntimeError("%s: %r reads a%d, loaded by the asm ds_read at instruction %d, with no s_waitcnt lgkmcnt(0) in between"
-                                       % (name, s, hit[0], pending[hit[0]]))
+                if kind != "a":
+                    continue
+                for qi, qregs, _ in queue:
+                    if regs & qregs:
+                        raise RuntimeError("%s: %r reads a%d, loaded by the ds_read at instruction %d, which no s_waitcnt in between retires"
+                                           % (name, s, min(regs & qregs), qi))
     return n
 
 
@@ -241,6 +253,12 @@ def check_unit(unit, obj, verbose=True):
         if na == 0 or nb == 0:
             raise RuntimeError("mlpbf.hip: the checks found nothing to check (%d AGPR fragment reads, %d counted publishes): the patterns moved" % (na, nb))
         msg.append("%d asm fragment reads waited for, %d counted publishes with exactly 16 stores behind the last DMA piece" % (na, nb))
+    if unit == "mlphf.hip":                  # the f16x3 chains: the same two invariants, eight stores behind the last piece (mlphf.hip hf_slot)
+        na = sum(check_agpr_fragment_reads(n, i) for n, i in ks.items())
+        nb = sum(check_counted_publish(n, i, keep=8) for n, i in ks.items())
+        if na == 0 or nb == 0:
+            raise RuntimeError("mlphf.hip: the checks found nothing to check (%d AGPR fragment reads, %d counted publishes): the patterns moved" % (na, nb))
+        msg.append("%d asm fragment reads waited for, %d counted publishes with exactly 8 stores behind the last DMA piece" % (na, nb))
     if unit == "dw.hip" and dw_slotted_expected():
         k = [n for n in ks if "k_dw_bf" in n and "Li6E" in n]
         assert len(k) == 1, list(ks)
@@ -254,5 +272,5 @@ def check_unit(unit, obj, verbose=True):
 if __name__ == "__main__":
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for u in sys.argv[1:] or ["mlpbf.hip", "dw.hip", "mlp.hip", "mlp16.hip", "elem.hip"]:
+    for u in sys.argv[1:] or ["mlpbf.hip", "mlphf.hip", "dw.hip", "mlp.hip", "mlp16.hip", "elem.hip"]:
         check_unit(u, os.path.join(here, "build", u.replace(".hip", ".o")))

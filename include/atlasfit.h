@@ -20,7 +20,8 @@ extern "C" {
 
 typedef struct af_handle af_handle;
 
-enum af_status { AF_OK = 0, AF_EINVAL = -1, AF_EHIP = -2, AF_ENOMEM = -3, AF_ENAN = -4, AF_ESTATE = -5 };
+enum af_status { AF_OK = 0, AF_EINVAL = -1, AF_EHIP = -2, AF_ENOMEM = -3, AF_ENAN = -4, AF_ESTATE = -5,
+                 AF_ERANGE = -6   /* af_set_mlp_mode(h, 3) only: a hidden-layer weight left the range its fp16 images are scaled for (|w| >= 8) */ };
 enum af_net { AF_MAPPING1 = 0, AF_ATLAS = 1, AF_MAPPING2 = 2, AF_ALPHA = 3 };
 
 /* Mirrors the keys of src/config/config_flow_100.json that the loop reads
@@ -167,7 +168,10 @@ int af_set_dw_mode(af_handle* h, int mode);
 int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost);
 /* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
  * = bf16x6, 0 = fp32 matrix pipe, 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16
- * operands — a measured experiment, not a default.  (Python mirror: AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.)
+ * operands — a measured experiment, not a default.  3 = "f16x3" (mlphf.hip, round 6): every operand as two fp16 terms of its scaled
+ * value, three products on v_mfma_f32_32x32x16_f16, a power-of-two scale per ROW and layer on the activations / gradients and a fixed 2^12 on the
+ * weights; af_train_steps / af_pretrain return AF_ERANGE once a hidden-layer weight reaches |w| >= 8 (the images stay finite up to 16).
+ * (Python mirror: AtlasFit(cfg, experiment_env=True) maps AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.)
  * pre_train_mapping's MLP chains always run the fp32 16-row kernels (mlp16.hip); its weight-gradient GEMM follows af_set_dw_mode. */
 int af_set_mlp_mode(af_handle* h, int mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */

@@ -36,17 +36,18 @@ def test_mlp_modes_agree_at_full_size(two_layer):
     g = torch.Generator().manual_seed(13)
     rows = np.zeros((4096, 4), np.float32); rows[:, :3] = torch.rand(4096, 3, generator=g).numpy() * 2 - 1
     fw = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         af.set_mlp_mode(mode)
         fw[mode] = {net: af.debug_forward(net, rows) for net in af.nets}
     for net in af.nets:
-        d = np.abs(fw[1][net] - fw[0][net]).max()
-        print("two_layer", two_layer, "net", net, "forward max |bf16x6 - fp32 MFMA| %.3g" % d)
+        d, d3 = np.abs(fw[1][net] - fw[0][net]).max(), np.abs(fw[3][net] - fw[0][net]).max()
+        print("two_layer", two_layer, "net", net, "forward max |bf16x6 - fp32 MFMA| %.3g   |f16x3 - fp32 MFMA| %.3g" % (d, d3))
         assert d < 3e-6, (net, d)
+        assert d3 < 3e-6, (net, d3)
     for it in (0, 6000):
         inds = torch.randint(F * resx * resy, (af.N,), generator=g).numpy()
         res = {}
-        for mode in (0, 1, 2):                           # 2: the forward of mode 1, backward chain on three products (experiment)
+        for mode in (0, 1, 2, 3):                        # 2: the forward of mode 1, backward chain on three products (experiment); 3: f16x3 (mlphf.hip)
             af.set_mlp_mode(mode)
             for net in af.nets:
                 af.load_state_dict(net, sds[net])
@@ -67,6 +68,12 @@ def test_mlp_modes_agree_at_full_size(two_layer):
             print("iter", it, "net", net, "gradient rel (L2) bf16x6 vs fp32 MFMA chains %.3g ; three-product backward chain vs bf16x6 %.3g" % (r, r3))
             assert r < 1e-3, (it, net, r)      # forward differences of ~2e-7 in uv are amplified by the finite-difference rigidity terms
             assert r3 < 3e-4, (it, net, r3)    # 16-bit-mantissa operands in dX = W^T dZ
+            rh = np.linalg.norm(res[3][1][net] - g0) / np.linalg.norm(g0)
+            print("iter", it, "net", net, "gradient rel (L2) f16x3 vs fp32 MFMA chains %.3g" % rh)
+            assert rh < 1e-3, (it, net, rh)    # the same bound bf16x6 is held to
+        relh = np.abs(res[3][0][:n] - res[0][0][:n]) / np.maximum(np.abs(res[0][0][:n]), 1e-9)
+        print("iter", it, "loss terms rel, f16x3 vs fp32 MFMA", relh.max())
+        assert relh.max() < 2e-5, (it, res[3][0], res[0][0])
     af.set_mlp_mode(1)
     af.close()
     del video
