@@ -7,6 +7,7 @@ loop body.  torch is imported first so the library binds to torch's HIP runtime 
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -22,7 +23,7 @@ ABI_SYMBOLS = [
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
     "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_debug_step_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
-    "af_debug_set_dw_cost",
+    "af_debug_set_dw_cost", "af_debug_tiles",
 ]
 
 
@@ -177,6 +178,7 @@ def load_library(path=None):
         "af_set_dw_mode": (i32, [vp, i32]),
         "af_set_mlp_mode": (i32, [vp, i32]),
         "af_debug_set_dw_cost": (i32, [vp, vp, C.c_double]),
+        "af_debug_tiles": (i32, [vp, i32, i32, i32, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -310,18 +312,33 @@ class AtlasFit:
     def _apply_experiment_env(self):
         """The A/B tools' environment switches, mapped onto the explicit calls (libatlasfit.so itself reads no environment):
         AF_MLP_MODE / AF_MLP_FP32, AF_DW_MODE / AF_DW_FP32 (include/atlasfit.h: af_set_mlp_mode, af_set_dw_mode) and
-        AF_DW_COST="c8x8,c8x2,c8x1,c1x8,c1x2[,seg]" (af_debug_set_dw_cost; tools/dw_cost_sweep.sh)."""
+        AF_DW_COST="c8x8,c8x2,c8x1,c1x8,c1x2[,seg]" (af_debug_set_dw_cost; tools/dw_cost_sweep.sh).
+        Honoured ONLY under AF_EXPERIMENT=1 (a stale exported AF_*MODE must not switch the arithmetic of a production run silently), every
+        override is reported on stderr, and `self.arithmetic` records what is in force (stage1.py writes it into the results' config.json)."""
         env = os.environ
-        if env.get("AF_MLP_FP32") and int(env["AF_MLP_FP32"]):
-            self.set_mlp_mode(0)
-        elif env.get("AF_MLP_MODE"):
-            self.set_mlp_mode(int(env["AF_MLP_MODE"]))
-        if env.get("AF_DW_FP32") and int(env["AF_DW_FP32"]):
-            self.set_dw_mode(0)
-        elif env.get("AF_DW_MODE"):
-            self.set_dw_mode(int(env["AF_DW_MODE"]))
-        if env.get("AF_DW_COST"):
-            self.set_dw_cost(env["AF_DW_COST"])
+        self.arithmetic = {"mlp_mode": 1, "dw_mode": 1, "dw_cost": None, "overrides": []}
+        asked = [k for k in ("AF_MLP_FP32", "AF_MLP_MODE", "AF_DW_FP32", "AF_DW_MODE", "AF_DW_COST") if env.get(k)]
+        if not asked:
+            return
+        if env.get("AF_EXPERIMENT", "0") in ("", "0"):
+            sys.stderr.write("[atlasfit] ignoring %s: experiment switches need AF_EXPERIMENT=1\n" % ", ".join("%s=%s" % (k, env[k]) for k in asked))
+            return
+        try:
+            if env.get("AF_MLP_FP32") and int(env["AF_MLP_FP32"]):
+                self.set_mlp_mode(0)
+            elif env.get("AF_MLP_MODE"):
+                self.set_mlp_mode(int(env["AF_MLP_MODE"]))
+            if env.get("AF_DW_FP32") and int(env["AF_DW_FP32"]):
+                self.set_dw_mode(0)
+            elif env.get("AF_DW_MODE"):
+                self.set_dw_mode(int(env["AF_DW_MODE"]))
+            if env.get("AF_DW_COST"):
+                self.set_dw_cost(env["AF_DW_COST"])
+        except Exception:
+            self.close()
+            raise
+        self.arithmetic["overrides"] = ["%s=%s" % (k, env[k]) for k in asked]
+        sys.stderr.write("[atlasfit] AF_EXPERIMENT: %s -> mlp_mode %d, dw_mode %d\n" % (", ".join(self.arithmetic["overrides"]), self.arithmetic["mlp_mode"], self.arithmetic["dw_mode"]))
 
     def close(self):
         if getattr(self, "h", None):
@@ -427,6 +444,18 @@ class AtlasFit:
         self._chk(self.lib.af_debug_forward(self.h, net, _ptr(rows), rows.shape[0], _ptr(out)))
         return out
 
+    def debug_tiles(self, net, which, layer, rows, tile0=0, ntiles=None):
+        """Tensors the last training step left for the weight-gradient GEMMs (include/atlasfit.h af_debug_tiles): which = "acts" (plane `layer` =
+        relu(Z_layer), (ntiles, 256, 32)), "dz" (dZ_layer), "masks" ((ntiles, 64, 4) uint32), "pe" ((ntiles, 64, 32)), "dz_last" / "x0" ((ntiles, 32, 32)).
+        `rows` = rows of that net's batch in the step (its planes are ceil(rows / 32) tiles apart)."""
+        kinds = {"acts": (0, (256, 32)), "dz": (1, (256, 32)), "masks": (2, (64, 4)), "pe": (3, (64, 32)), "dz_last": (4, (32, 32)), "x0": (5, (32, 32))}
+        code, shp = kinds[which]
+        stride = (int(rows) + 31) // 32
+        ntiles = stride - tile0 if ntiles is None else int(ntiles)
+        out = np.empty((ntiles,) + shp, np.float32)
+        self._chk(self.lib.af_debug_tiles(self.h, net, code, int(layer), stride, int(tile0), ntiles, _ptr(out)))
+        return out.view(np.uint32) if which == "masks" else out
+
     def read_records(self, inds):
         """(n, 16) packed pixel records for pixel-frame indices `inds` (column numbers of get_tuples' table)."""
         inds = np.ascontiguousarray(inds, np.int64)
@@ -465,6 +494,8 @@ class AtlasFit:
     def set_dw_mode(self, mode):
         """k_dw arithmetic: 1 = bf16x6 (fp32-faithful; the default), 2 = bf16x3 (two bf16 per operand, three products: narrower than fp32, opt-in), 0 = fp32 MFMA."""
         self._chk(self.lib.af_set_dw_mode(self.h, int(mode)))
+        if hasattr(self, "arithmetic"):
+            self.arithmetic["dw_mode"] = int(mode)
 
     def set_dw_cost(self, row, seg_cost=0.0):
         """Another split-K partition of k_dw (af_debug_set_dw_cost): row = five tile costs (8x8, 8x2, 8x1, 1x8, 1x2), a sequence or the
@@ -486,6 +517,8 @@ class AtlasFit:
         """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check),
         2 = bf16x6 forward, three-product backward chain (experiment)."""
         self._chk(self.lib.af_set_mlp_mode(self.h, int(mode)))
+        if hasattr(self, "arithmetic"):
+            self.arithmetic["mlp_mode"] = int(mode)
 
     def set_debug(self, on=True):
         self._chk(self.lib.af_set_debug(self.h, int(on)))

@@ -1405,6 +1405,29 @@ int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* ou
   return AF_OK;
 }
 
+int af_debug_tiles(af_handle* h, int net, int which, int layer, int nt_stride, int tile0, int ntiles, float* out) {
+  if (!h || !out || ntiles <= 0 || tile0 < 0 || layer < 0 || nt_stride <= 0) return AF_EINVAL;
+  if (net < 0 || net >= AF_MAX_NETS || !h->nets[net].used) return h->fail(AF_EINVAL, "unknown net");
+  const NetDesc& n = h->nets[net];
+  if (tile0 + ntiles > nt_stride || nt_stride > n.nt_cap) return h->fail(AF_EINVAL, "af_debug_tiles: tile range");
+  const float* src = nullptr; size_t per = 0; bool planes = false;
+  switch (which) {
+    case 0: src = n.acts; per = AF_TILE_F; planes = true; break;                 // plane l = relu(Z_l) = X_{l+1}, T-layout [256][32]
+    case 1: src = n.dz; per = AF_TILE_F; planes = true; break;                   // plane l = dZ_l
+    case 2: src = (const float*)n.masks; per = 64 * 4; planes = true; break;     // plane l = sign bits of X_{l+1}, [64 lanes][4 words]
+    case 3: src = n.pe_tile; per = 2048; break;                                  // PE features [64][32]
+    case 4: src = n.dz_last; per = 1024; break;                                  // dZ of the output layer [32][32]
+    case 5: src = n.x0_tile; per = 1024; break;                                  // xyt rows [32][32] (mapping nets without PE)
+    default: return h->fail(AF_EINVAL, "af_debug_tiles: which");
+  }
+  if (!src || (which == 3 && !n.pe_feats)) return h->fail(AF_EINVAL, "af_debug_tiles: this net has no such tensor");
+  if (planes && layer >= n.NL - 1) return h->fail(AF_EINVAL, "af_debug_tiles: layer");
+  HCHK(hipSetDevice(h->device)); HCHK(hipStreamSynchronize(h->stream));
+  const size_t off = ((planes ? (size_t)layer * nt_stride : 0) + tile0) * per;
+  HCHK(hipMemcpy(out, src + off, (size_t)ntiles * per * 4, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
 int af_render_frame(af_handle* h, int frame, float* rgb_out, double* sse_out) {
   if (!h) return AF_EINVAL;
   if (frame < 0 || frame >= h->cfg.number_of_frames) return h->fail(AF_EINVAL, "af_render_frame: frame index");

@@ -129,6 +129,12 @@ int af_sync(af_handle* h);
 /* ---- test / measurement hooks (not part of the reference surface) --------------------------------- */
 /* Run one net forward on caller rows: in [rows][4] host -> out [rows][4] host. */
 int af_debug_forward(af_handle* h, int net, const float* in, int rows, float* out);
+/* Debug: the tensors the LAST training step left in HBM for the weight-gradient GEMMs, as the kernels wrote them (per row tile of 32 rows):
+ * which = 0 activation plane `layer` (relu(Z_layer) = X_{layer+1}, [256 features][32 rows]), 1 gradient plane (dZ_layer), 2 its sign-bit words
+ * (copied as 256 x 32-bit per tile), 3 the PE features [64][32], 4 dZ of the output layer [32][32], 5 the xyt rows [32][32].  nt_stride = row tiles per
+ * plane of that step (ceil(rows of the net's batch / 32)); `ntiles` tiles from `tile0` go to out.  What tests/test_gpu_gemm_error.py measures the
+ * per-layer error of each arithmetic on: one layer's product recomputed in fp64 from the kernel's OWN inputs against the kernel's output. */
+int af_debug_tiles(af_handle* h, int net, int which, int layer, int nt_stride, int tile0, int ntiles, float* out);
 /* The launch plan of the single-atlas step for a chip of `ncu` compute units (pure arithmetic, no GPU needed):
  * out3 = {T1, T2, NT}: mapping row tiles [0,T1) form launch 1, [T1,T2) lead and [T2,NT) trail the atlas part of
  * launch 2 (DESIGN.md §2.1 "Packed launches"). */
