@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "af_render_frame", "af_psnr", "af_sync", "af_debug_forward", "af_set_debug", "af_get_last_grads",
     "af_set_timing", "af_get_timing", "af_step_work", "af_loss_width", "af_config_size", "af_debug_records", "af_debug_plan",
     "af_resize_bilinear", "af_flow_consistency", "af_debug_dw_clocks", "af_debug_step_clocks", "af_set_dw_mode", "af_set_mlp_mode", "af_debug_dw_schedule",
-    "af_debug_set_dw_cost", "af_debug_tiles",
+    "af_debug_set_dw_cost", "af_debug_tiles", "af_get_modes",
 ]
 
 
@@ -179,6 +179,7 @@ def load_library(path=None):
         "af_set_mlp_mode": (i32, [vp, i32]),
         "af_debug_set_dw_cost": (i32, [vp, vp, C.c_double]),
         "af_debug_tiles": (i32, [vp, i32, i32, i32, i32, i32, i32, vp]),
+        "af_get_modes": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -316,7 +317,9 @@ class AtlasFit:
         Honoured ONLY under AF_EXPERIMENT=1 (a stale exported AF_*MODE must not switch the arithmetic of a production run silently), every
         override is reported on stderr, and `self.arithmetic` records what is in force (stage1.py writes it into the results' config.json)."""
         env = os.environ
-        self.arithmetic = {"mlp_mode": 1, "dw_mode": 1, "dw_cost": None, "overrides": []}
+        m, d = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.af_get_modes(self.h, C.byref(m), C.byref(d)))
+        self.arithmetic = {"mlp_mode": int(m.value), "dw_mode": int(d.value), "dw_cost": None, "overrides": []}
         asked = [k for k in ("AF_MLP_FP32", "AF_MLP_MODE", "AF_DW_FP32", "AF_DW_MODE", "AF_DW_COST") if env.get(k)]
         if not asked:
             return

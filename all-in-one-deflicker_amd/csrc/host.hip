@@ -541,11 +541,19 @@ AdamHyper adam_hyper(double lr, long long step) {
   return hy;
 }
 
+// The weight views k_adam keeps current: the canonical parameters, the fp32 images (mlp.hip, and always mlp16.hip's pre-train chains) and the
+// 16-bit chain streams of the arithmetic in force ONLY (bf16 h/m/l for modes 1 and 2, fp16 h/l for mode 3: 12 resp. 8 scattered 2-byte
+// stores per hidden weight that the other mode never reads); af_set_mlp_mode re-emits everything when the set changes.
+AdamBufs adam_bufs(af_handle* h, float* m, float* v) {
+  const bool bf = h->mlp_mode == 1 || h->mlp_mode == 2, hf = h->mlp_mode == 3;
+  return {h->params, m, v, h->img_f, h->img_b, h->bias_img, bf ? h->img_sf : nullptr, bf ? h->img_sb : nullptr, hf ? h->img_hf : nullptr, hf ? h->img_hb : nullptr};
+}
+
 // re-emit the GEMM weight views of the jobs of a schedule from the canonical parameters
 int repack(af_handle* h, Sched& sc) {
   AdamArgs a{};
   a.jobs = sc.d_ajobs; a.partial = h->partial;
-  a.bufs = {h->params, h->adam_m, h->adam_v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb, h->img_hf, h->img_hb};
+  a.bufs = adam_bufs(h, h->adam_m, h->adam_v);
   a.nan_flag = h->nan_flag;
   LCHK(af_launch_adam(&a, (int)sc.ajobs.size(), 0, h->stream));
   return 0;
@@ -615,7 +623,7 @@ int finish_step(af_handle* h, Sched& sc, float* m, float* v, long long step, flo
     Timer t(h, T_ADAM);
     AdamArgs a{};
     a.jobs = sc.d_ajobs; a.partial = h->partial;
-    a.bufs = {h->params, m, v, h->img_f, h->img_b, h->bias_img, h->img_sf, h->img_sb, h->img_hf, h->img_hb};
+    a.bufs = adam_bufs(h, m, v);
     a.hy = adam_hyper(h->cfg.lr, step);
     a.grad_out = h->debug ? h->grads : nullptr;
     a.loss_part = h->loss_part; a.loss_out = loss_out; a.counts = h->counts; a.loss_nblk = loss_nblk; a.nan_flag = h->nan_flag;
@@ -1142,7 +1150,19 @@ int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost) {
 int af_set_mlp_mode(af_handle* h, int mode) {
   if (!h) return AF_EINVAL;
   if (mode < 0 || mode > 3) return h->fail(AF_EINVAL, "af_set_mlp_mode: 0 (fp32 MFMA), 1 (bf16x6), 2 (bf16x6 forward, three-product bf16 backward chain) or 3 (f16x3: two-term fp16 split with a scale per row)");
+  const int cls_old = h->mlp_mode == 3 ? 2 : (h->mlp_mode ? 1 : 0), cls_new = mode == 3 ? 2 : (mode ? 1 : 0);
   h->mlp_mode = mode;
+  if (cls_new != cls_old && cls_new != 0) {      // another set of 16-bit streams comes into use: bring it up to date (k_adam only maintains the set in force)
+    HCHK(hipSetDevice(h->device));
+    const int rc = repack(h, h->sched[0]); if (rc) return rc;
+    HCHK(hipStreamSynchronize(h->stream));
+  }
+  return AF_OK;
+}
+int af_get_modes(const af_handle* h, int* mlp_mode, int* dw_mode) {
+  if (!h) return AF_EINVAL;
+  if (mlp_mode) *mlp_mode = h->mlp_mode;
+  if (dw_mode) *dw_mode = h->dw_mode;
   return AF_OK;
 }
 int af_set_debug(af_handle* h, int enable) { if (!h) return AF_EINVAL; h->debug = enable != 0; return AF_OK; }

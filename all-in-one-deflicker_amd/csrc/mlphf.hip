@@ -39,6 +39,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define AF_HF_WSHIFT 12                 // the weight images hold 2^12 W (elem.hip emit_hf2 uses the same constant)
 #define AF_HF_KEEP 8                    // tile stores younger than the last DMA piece of a chunk at its publish (see hf_slot)
 
+#ifdef AF_HF_CLK      // tools/hfbench.hip: s_memtime at the seams of a chain (wave 0 of every workgroup): where the ticks of a task go
+__device__ unsigned long long* g_hf_clk;
+#define HF_MARK(i) do { if (g_hf_clk && threadIdx.x == 0) g_hf_clk[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HF_MARK(i) do { } while (0)
+#endif
+
 template <class NS> struct ChunkBytesHf {
   static constexpr int L0 = ChunkBytes<NS>::L0;
   static constexpr int HID = AF_SLOT_HF;                 // x4 per hidden layer
@@ -339,12 +346,17 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
 
   // ---- layer 0 (fp32 block); the chunk behind it is the first fp16 chunk of layer 1
+  HF_MARK(1);
   const char* cur = cs.publish(CB::L0);             // its barrier also publishes the bias rows
+  HF_MARK(2);
   init_bias(acc, bias_lds, 0, h);
   mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
+  HF_MARK(3);
   relu_out(0, std::false_type{});
+  HF_MARK(4);
   const char* lane_base = cs.publish(nl > 2 ? CB::HID : CB::last_bytes(nl)) + lane_off;     // what lies behind layer 0: the first hidden chunk, or the output layer
   cs.lead5();
+  HF_MARK(5);
 
   // ---- hidden layers 1 .. NL-2: four fp16 chunks each (+ the fp32 block of the skip columns)
   if constexpr (HID) {
@@ -368,7 +380,9 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
         cs.lead5();
       }
     }
+    HF_MARK(4 + 2 * l);
     relu_out(l, std::true_type{});
+    HF_MARK(5 + 2 * l);
   } while (++l <= nl - 2);
   }
   lane_base -= lane_off;
@@ -410,6 +424,7 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
     }
     if (live && h == 0) *(f32x4*)(a.out + (size_t)row * 4) = o;
   }
+  HF_MARK(30);
 }
 
 // x if bit (31 - e) of the sign-mask word is set, else 0 (mlpbf.hip bf_mask_keep)
@@ -481,18 +496,25 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
 
   // ---- output layer (fp32 block): K = 8 (one group), only p < OUT non-zero
+  HF_MARK(1);
   const char* cur = cs.publish(CB::BLAST);
+  HF_MARK(2);
   mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
+  HF_MARK(3);
   mask_out(nl - 1, std::false_type{});
+  HF_MARK(4);
   const char* lane_base = cs.publish(nl > 2 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096)) + lane_off;
   cs.lead5();
+  HF_MARK(5);
 
 #pragma unroll 1
   for (int l = nl - 2; l >= 1; --l) {
     hf_enter(pp, in, sc, lane_base);
     // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
     hf_block<!(AF_ABL & 1)>(acc, in, sc, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), ts);
+    HF_MARK(4 + 2 * (nl - 1 - l));
     mask_out(l, std::true_type{});
+    HF_MARK(5 + 2 * (nl - 1 - l));
   }
   lane_base -= lane_off;
 
@@ -529,6 +551,7 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
     ts.template part<0>(in); ts.template part<1>(in); ts.template part<2>(in); ts.template part<3>(in);
     ts.template part<4>(in); ts.template part<5>(in); ts.template part<6>(in); ts.template part<7>(in);
   }
+  HF_MARK(30);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +559,7 @@ template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_hf(MultiFwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AF_STAMP(m, 0);
+  HF_MARK(0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }
@@ -552,6 +576,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_multi_hf(MultiFwd m) {
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd_multi_hf(MultiBwd m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AF_STAMP(m, 0);
+  HF_MARK(0);
   int s = 0, base = 0;
   const int wg = blockIdx.x;
   while (s + 1 < m.n && wg >= m.wg_end[s]) { base = m.wg_end[s]; ++s; }

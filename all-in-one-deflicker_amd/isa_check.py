@@ -208,16 +208,18 @@ def check_dw_slots(name, ins):
 
 
 def check_valu_write_to_mfma_read(name, ins, need=2):
-    """(d) every v_mfma: its SrcA / SrcB VGPRs were not written by a VALU instruction within the last `need` wait states (s_nop N = N + 1
-    wait states, any other instruction 1).  Scanned linearly over the kernel: a pair across a branch target can only make it stricter."""
+    """(d) every v_mfma: its SrcA / SrcB (and SrcC, when that is a VGPR) registers were not written by a VALU instruction within the last `need` wait
+    states (s_nop N = N + 1 wait states, any other instruction 1).  Checked on the STRAIGHT-LINE instruction order of the kernel: a writer at a loop
+    tail feeding an MFMA at the loop head across the back-edge is not followed (the chains' loops start with LDS reads and waits, never with an MFMA),
+    and only the first destination of a writer is looked at."""
     n = 0
     for i, s in enumerate(ins):
         if not s.startswith("v_mfma"):
             continue
         ops = [t.strip() for t in s.split(None, 1)[1].split(",")]
         srcs = set()
-        for t in ops[1:3]:
-            kind, regs = _regs(t.split()[0])
+        for t in ops[1:4]:
+            kind, regs = _regs(t.split()[0]) if t else (None, set())
             if kind == "v":
                 srcs |= regs
         n += 1

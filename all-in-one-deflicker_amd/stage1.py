@@ -356,6 +356,8 @@ def evaluate_model_single(af, video_frames, results_folder, iteration, save_chec
             rec, sse = af.render_frame(f)
             jobs.append(ex.submit(write, f, rec))
             psnrs[f] = 10.0 * np.log10(1.0 / (sse / rec.size))
+            if len(jobs) > 16:          # renders outrun the PNG encodes: at most 16 frames (25 MB each at 1080p) wait in the queue
+                jobs.pop(0).result()
         for j in jobs:
             j.result()
     print(psnrs.mean())
@@ -392,6 +394,11 @@ def main(config, args, two_layer=False):
     dev_ord = getattr(args, "device_ordinal", 0)
     F = count_input_frames(config["maximum_number_of_frames"], data_folder)
     af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=dev_ord)
+    # the arithmetic of this run next to its configuration (include/atlasfit.h af_set_mlp_mode / af_set_dw_mode; AF_EXPERIMENT overrides named)
+    with open(results_folder / "config.json", "w") as f:
+        json.dump(dict(config, atlasfit_arithmetic=af.arithmetic), f, indent=4)
+    if af.arithmetic["overrides"]:
+        print("arithmetic overrides in force:", af.arithmetic)
     # Random draws: the reference uses torch's process-global RNG.  With --seed (an extension) every draw of this call comes
     # from its own torch.Generator, so concurrent videos in one process (launch_videos.py --concurrent) stay reproducible
     # and independent; without it the global RNG is used like the reference does.
@@ -443,7 +450,8 @@ def main(config, args, two_layer=False):
                                        with_masks=two_layer, device=dev_ord)
             flows_mask, video_frames, flows_rev_mask, flows_rev, flows = t[:5]
             mask_frames = t[5] if two_layer else None
-        assert video_frames.shape[3] == F
+        if video_frames.shape[3] != F:      # the handle (and the pre-train running on it) was sized from the directory listing
+            raise RuntimeError("the loader produced %d frames, the handle was created for %d (files changed under %s?)" % (video_frames.shape[3], F, data_folder))
     except BaseException:       # a missing flow / mask file: the pre-train thread still owns the handle — let it finish before the handle goes away
         if pre is not None:
             pre.join()

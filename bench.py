@@ -28,15 +28,32 @@ HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E 8 TB/s spec (6.3 TB/s
 DW_TILE_BYTES = {"map1": 328 * 1024, "atlas": 512 * 1024, "map2": 200 * 1024, "alpha": 460 * 1024}
 METRIC = "atlas-fit sampled points/sec (stage1, 10k iters) @1/2/4/8 GPU; PSNR vs ref"     # BASELINE.json "metric"
 # launch classes of af_get_timing -> kernel names as rocprofv3 prints them
-MLP_MODE = 0 if os.environ.get("AF_MLP_FP32") else int(os.environ.get("AF_MLP_MODE", "1"))     # 1: hidden-layer products on the bf16 matrix pipe, fp32-faithful (mlpbf.hip); 2: backward chain on three products (experiment)
-MLP_BF = MLP_MODE != 0
-DW_MODE = 0 if os.environ.get("AF_DW_FP32") else int(os.environ.get("AF_DW_MODE", "1"))     # k_dw arithmetic (host.hip): 1 = bf16x6 (fp32-faithful, the default and the headline), 2 = bf16x3 (opt-in, narrower than fp32), 0 = fp32 MFMA
-DW_BF = DW_MODE != 0
-DW_PRODUCTS = {0: 1, 1: 6, 2: 3}[DW_MODE]
-_FWD = "k_mlp_fwd_multi_bf<true>" if MLP_BF else "k_mlp_fwd_multi<true>"
-_BWD = ("k_mlp_bwd_multi_bf3" if MLP_MODE == 2 else "k_mlp_bwd_multi_bf") if MLP_BF else "k_mlp_bwd_multi"
-KERNEL_OF_CLASS = {"fwd_1": _FWD, "fwd_2": _FWD, "bwd_1": _BWD, "bwd_2": _BWD, "dw": ("k_dw_bf<%d>" % DW_PRODUCTS) if DW_BF else "k_dw",
-                   "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
+F16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0    # fp16 MFMA runs at the bf16 rate (same guide); an fp32-faithful product = three fp16 partial products (mlphf.hip): 833.3 TF
+# The arithmetic modes are the LIBRARY's (af_get_modes; include/atlasfit.h af_set_mlp_mode / af_set_dw_mode): 3 = f16x3 chains (two-term fp16 split with a scale
+# per row, three products: the default since round 6), 1 = bf16x6, 2 = bf16x6 forward + three-product bf16 backward (experiment), 0 = fp32 MFMA;
+# k_dw: 1 = bf16x6 (default), 2 = bf16x3 (opt-in, narrower than fp32), 0 = fp32 MFMA.  AF_EXPERIMENT=1 AF_MLP_MODE=<m> / AF_DW_MODE=<m> select another (atlasfit.py).
+MLP_MODE, DW_MODE = 3, 1          # set from the handle in main() (configure_modes)
+MLP_BF, DW_BF, DW_PRODUCTS, KERNEL_OF_CLASS = True, True, 6, {}
+
+
+def configure_modes(mlp_mode, dw_mode):
+    """Kernel names as rocprofv3 prints them and the peak of each arithmetic, for the modes the handle runs in."""
+    global MLP_MODE, DW_MODE, MLP_BF, DW_BF, DW_PRODUCTS, KERNEL_OF_CLASS
+    MLP_MODE, DW_MODE = int(mlp_mode), int(dw_mode)
+    MLP_BF, DW_BF = MLP_MODE != 0, DW_MODE != 0
+    DW_PRODUCTS = {0: 1, 1: 6, 2: 3}[DW_MODE]
+    fwd = {0: "k_mlp_fwd_multi<true>", 3: "k_mlp_fwd_multi_hf<true>"}.get(MLP_MODE, "k_mlp_fwd_multi_bf<true>")
+    bwd = {0: "k_mlp_bwd_multi", 2: "k_mlp_bwd_multi_bf3", 3: "k_mlp_bwd_multi_hf"}.get(MLP_MODE, "k_mlp_bwd_multi_bf")
+    KERNEL_OF_CLASS = {"fwd_1": fwd, "fwd_2": fwd, "bwd_1": bwd, "bwd_2": bwd, "dw": ("k_dw_bf<%d>" % DW_PRODUCTS) if DW_BF else "k_dw",
+                       "prep": "k_prep", "loss": "k_loss", "adam": "k_adam<true>"}
+
+
+def chain_peak_tflops():
+    """Dense matrix-pipe peak of fp32-faithful work for the chains' arithmetic: never the raw 16-bit peak."""
+    return {0: FP32_MFMA_PEAK_TFLOPS, 3: F16X3_PEAK_TFLOPS}.get(MLP_MODE, BF16X6_PEAK_TFLOPS)
+
+
+configure_modes(3, 1)
 
 
 def _remap_zero(img, mapx, mapy):
@@ -351,6 +368,8 @@ CHAIN_HIDDEN = {"map1": 5, "atlas": 7, "map2": 3, "alpha": 7}
 CHAIN_PE_BYTES = {"map1": 0, "atlas": 160, "map2": 0, "alpha": 128}
 # bf16 h/m/l weight stream of one orientation: 256x256 hidden layers x 3 levels x 2 B; every XCD's L2 (8 of them) fetches it once per launch
 CHAIN_STREAM_BYTES = {"map1": 4 * 393216, "atlas": 6 * 393216, "map2": 2 * 393216, "alpha": 6 * 393216}
+# f16x3 chains: two fp16 levels per 256x256 hidden layer
+CHAIN_STREAM_BYTES_HF = {"map1": 4 * 262144, "atlas": 6 * 262144, "map2": 2 * 262144, "alpha": 6 * 262144}
 
 
 def hbm_model_bytes(kernel, rows4, launches_per_step):
@@ -362,7 +381,8 @@ def hbm_model_bytes(kernel, rows4, launches_per_step):
     per_row = {n: CHAIN_HIDDEN[n] * (1024 + 32) + CHAIN_PE_BYTES[n] + 32 for n in r}
     if kernel.startswith("k_mlp_bwd"):
         per_row["map1"] += 128; per_row["map2"] += 128     # dz of layer 0's three inputs is not stored; the x0 tile is read by k_dw, not here
-    streams = 8 * sum(CHAIN_STREAM_BYTES[n] * (2 if n == "map1" else 1) for n in r if r[n] > 0)     # mapping1 has tiles in both launches of a direction
+    sb = CHAIN_STREAM_BYTES_HF if kernel.endswith(("_hf", "_hf<true>")) else CHAIN_STREAM_BYTES
+    streams = 8 * sum(sb[n] * (2 if n == "map1" else 1) for n in r if r[n] > 0)     # mapping1 has tiles in both launches of a direction
     return (sum(per_row[n] * r[n] for n in r) + streams) / launches_per_step
 
 
@@ -409,8 +429,12 @@ def main():
                     "per pixel: real RAFT masks are far from all-valid, and only valid rows are credited as algorithmic work (loss_utils.py:326-356)")
     args = ap.parse_args()
 
+    # AF_BENCH_SHARE_DEVICE=1 (a rehearsal, never a result): all ranks on GPU 0, gloo for the barrier / MAX since RCCL refuses two ranks on one
+    # device — everything of the N-rank path except N GPUs: N processes initialise, build their videos, pass the barrier-bracketed window, gather
+    # `ranks`, print ONE line (labelled).  The one-GPU box is the only hardware this repository has ever been given.
+    share = os.environ.get("AF_BENCH_SHARE_DEVICE", "0") not in ("", "0")
     if args.gpus > 1 and "RANK" not in os.environ:         # bare `python bench.py --gpus N`: spawn the N ranks ourselves
-        if not os.environ.get("AF_BENCH_DRY_RUN"):
+        if not os.environ.get("AF_BENCH_DRY_RUN") and not share:
             check_gpu_count(args.gpus)
         return self_spawn(args.gpus, sys.argv[1:])
     if os.environ.get("AF_BENCH_DRY_RUN"):
@@ -420,7 +444,9 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
-    n_visible = check_gpu_count(max(args.gpus, local + 1))      # a launcher that started more ranks than there are GPUs: say so, once per rank, before set_device
+    if share:
+        local = 0
+    n_visible = check_gpu_count(1 if share else max(args.gpus, local + 1))      # a launcher that started more ranks than there are GPUs: say so, once per rank, before set_device
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     torch.cuda.set_device(local)
@@ -429,12 +455,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if share else dev          # where the barrier's / all-reduce's tensors live
     assert args.gpus == world, "--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node == --gpus (or bare, without RANK in the environment)" % (args.gpus, world)
 
     cfg = aiod_amd.default_config(args.resx, args.resy, args.frames, two_layer=args.two_layer)
     N = cfg.samples_batch
     af = aiod_amd.AtlasFit(cfg, device=local)
+    configure_modes(af.arithmetic["mlp_mode"], af.arithmetic["dw_mode"])
     vseed = shard_for_rank(rank, world)[0]
     video = synth_video_device(args.resx, args.resy, args.frames, seed=vseed, device=dev)
     if args.valid_fraction < 1.0:
@@ -512,8 +543,8 @@ def main():
         got.update(losses=af.train_steps(first, K, None, seed=rank, return_losses=True))
         for t in ths:
             t.join()
-    dt = timed_region(run_all, torch.cuda.synchronize, dist if world > 1 else None, dev)
-    ranks = rank_stats(timed_region.local_seconds, K, torch.cuda.get_device_name(local), dist if world > 1 else None, dev)
+    dt = timed_region(run_all, torch.cuda.synchronize, dist if world > 1 else None, cdev)
+    ranks = rank_stats(timed_region.local_seconds, K, torch.cuda.get_device_name(local), dist if world > 1 else None, cdev)
     tk = af.timing(reset=True)
 
     # ---- per-kernel pass (NOT the timed region): the same K iterations once more, HIP events around every launch, clocks as
@@ -531,8 +562,15 @@ def main():
     if DW_MODE == 1 and not extra:
         af.set_dw_mode(2)
         af.train_steps(max(0, first - 5), 5, None, seed=rank + 60, return_losses=False)
-        dt3 = timed_region(lambda: af.train_steps(first, K, None, seed=rank + 61, return_losses=False), torch.cuda.synchronize, dist if world > 1 else None, dev)
+        dt3 = timed_region(lambda: af.train_steps(first, K, None, seed=rank + 61, return_losses=False), torch.cuda.synchronize, dist if world > 1 else None, cdev)
         af.set_dw_mode(1)
+    # ---- third value, never the headline: the same K steps with the chains on bf16x6 (the headline arithmetic of rounds 2-5), timed by the same rule
+    dt6 = None
+    if MLP_MODE == 3 and not extra:
+        af.set_mlp_mode(1)
+        af.train_steps(max(0, first - 5), 5, None, seed=rank + 70, return_losses=False)
+        dt6 = timed_region(lambda: af.train_steps(first, K, None, seed=rank + 71, return_losses=False), torch.cuda.synchronize, dist if world > 1 else None, cdev)
+        af.set_mlp_mode(3)
 
     # Only valid flow matches are evaluated (k_prep compacts them like the reference's torch.where); the library
     # accumulates FLOPs per launch from the planned rows, so the work of the rows behind the live count is taken out here
@@ -571,14 +609,15 @@ def main():
     flops_launch = (sum(tk[c][2] for c in dom_classes) - masked_of(dom, dom_classes, inv_sampled)) / n_launch
     achieved = flops_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     total_flops = sum(af.step_work(first + k)[1] for k in range(K)) - masked_step_flops
-    mfma_peak = (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS if DW_BF else FP32_MFMA_PEAK_TFLOPS) if is_dw else (BF16X6_PEAK_TFLOPS if MLP_BF else FP32_MFMA_PEAK_TFLOPS)
+    mfma_peak = (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS if DW_BF else FP32_MFMA_PEAK_TFLOPS) if is_dw else chain_peak_tflops()
     if is_dw and DW_BF:      # on the bf16 matrix pipe this kernel's 64 FLOP/B sit under the HBM roof: the roofline is bytes, not flops
         roof = {"bound": "hbm", "achieved": dw_alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": dw_alg_bytes}
     else:
         roof = {"bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["peak_definition"] = ("HBM3E 8 TB/s" if roof["bound"] == "hbm" else
-                               ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32-faithful product" if mfma_peak != FP32_MFMA_PEAK_TFLOPS else "FP32 MFMA peak"))
+                               ("FP32 MFMA peak" if mfma_peak == FP32_MFMA_PEAK_TFLOPS else
+                                "dense 16-bit MFMA peak 2500 TFLOP/s / %d partial products per fp32-faithful product" % round(BF16_MFMA_PEAK_TFLOPS / mfma_peak)))
     # every hot kernel by name, from the per-kernel pass above
     by_kernel = {"_source": "separate pass of the same %d iterations after the timed region, HIP events around every launch (%.4f ms/step wall with the events, "
                             "the timed region has them around the dominant kernel only)" % (K, dt_all_events / K * 1e3)}
@@ -589,6 +628,9 @@ def main():
             by_kernel[kname] = {"ms_per_step": ms / K, "launches_per_step": nl / K, "tflops": (fl / ms / 1e9) if fl > 0 else None,
                                 "frac_of_fp32_mfma_peak": (fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS) if fl > 0 else None,
                                 "frac_of_bf16x6_peak": (fl / ms / 1e9 / BF16X6_PEAK_TFLOPS) if fl > 0 else None}
+            if kname.startswith("k_mlp") and MLP_MODE == 3 and fl > 0:      # this kernel's own arithmetic: three fp16 products per product
+                by_kernel[kname]["frac_of_f16x3_peak"] = fl / ms / 1e9 / F16X3_PEAK_TFLOPS
+                by_kernel[kname].pop("frac_of_bf16x6_peak", None)
             if "dw" in cls:
                 if DW_BF and fl > 0 and DW_PRODUCTS != 6:      # this kernel's own arithmetic: DW_PRODUCTS bf16 products per product
                     by_kernel[kname]["frac_of_bf16x%d_peak" % DW_PRODUCTS] = fl / ms / 1e9 / (BF16X6_PEAK_TFLOPS * 6.0 / DW_PRODUCTS)
@@ -611,10 +653,11 @@ def main():
         value = world * V * N * K / dt
         out = {
             "metric": METRIC, "value": value, "unit": "sampled points/s",
-            "n_gpus": world, "n_gpus_visible": n_visible, "ranks": ranks, "steps": K, "warmup": W, "settle_steps": args.settle_steps, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "n_gpus": world, "n_gpus_visible": n_visible, **({"shared_device_rehearsal": "AF_BENCH_SHARE_DEVICE=1: all %d ranks on GPU 0 over gloo - exercises the multi-rank path, NOT a scaling result" % world} if share else {}), "ranks": ranks, "steps": K, "warmup": W, "settle_steps": args.settle_steps, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (" + "; ".join(x for x in (
-                ("MLP chains bf16x6: operands split into 3 bf16, 6 partial products" + (" (EXPERIMENT: backward chain on 3 products)" if MLP_MODE == 2 else "")) if MLP_BF else "",
+                ("MLP chains f16x3: operands split into 2 fp16 of their value scaled per row, 3 partial products" if MLP_MODE == 3 else
+                 "MLP chains bf16x6: operands split into 3 bf16, 6 partial products" + (" (EXPERIMENT: backward chain on 3 products)" if MLP_MODE == 2 else "")) if MLP_BF else "",
                 {1: "weight-gradient GEMM bf16x6", 2: "NON-DEFAULT weight-gradient GEMM bf16x3: 2 bf16 per operand, 3 partial products, narrower than fp32"}.get(DW_MODE, "")) if x)
                 + "; fp32 accumulate)") if (MLP_BF or DW_BF) else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: single video %d frames %dx%d, samples_batch %d, shipped config_flow_100.json; "
@@ -636,6 +679,11 @@ def main():
             out["value_bf16x3_dw"] = world * N * K / dt3
             out["ms_per_step_bf16x3_dw"] = dt3 / K * 1e3
             out["value_bf16x3_dw_note"] = "same K steps with af_set_dw_mode(h, 2): k_dw_bf<3>, 16-bit-mantissa operands, narrower than the reference's fp32 - not the headline"
+        if dt6 is not None:     # extra keys, never `value`: the chains on six bf16 products (rounds 2-5's headline arithmetic) on the same steps
+            out["value_bf16x6"] = world * N * K / dt6
+            out["ms_per_step_bf16x6"] = dt6 / K * 1e3
+            out["value_bf16x6_note"] = "same K steps with af_set_mlp_mode(h, 1): k_mlp_*_multi_bf, the fp32-faithful arithmetic of rounds 2-5, kept as the cross-check of f16x3"
+        out["arithmetic"] = af.arithmetic
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.resx, args.resy, args.frames, 0, sds, video, args.cpu_seconds, args.two_layer)

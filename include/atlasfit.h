@@ -180,6 +180,8 @@ int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost);
  * (Python mirror: AtlasFit(cfg, experiment_env=True) maps AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.)
  * pre_train_mapping's MLP chains always run the fp32 16-row kernels (mlp16.hip); its weight-gradient GEMM follows af_set_dw_mode. */
 int af_set_mlp_mode(af_handle* h, int mode);
+/* The arithmetic modes in force (either pointer may be NULL): what the host side records next to its results. */
+int af_get_modes(const af_handle* h, int* mlp_mode, int* dw_mode);
 /* After af_train_steps / af_pretrain with debug enabled: reduced gradient of the last step, flat order. */
 int af_set_debug(af_handle* h, int enable);
 int af_get_last_grads(af_handle* h, int net, float* flat, size_t n);

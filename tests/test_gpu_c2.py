@@ -95,7 +95,6 @@ def _run(seed, rec, partition, upto, v):
     return p_pre, p_at, p_end, np.concatenate(losses)
 
 
-@pytest.mark.skipif(not _records(), reason="no configs[1] reference record yet (tests/golden/c2_reference.npz or c2_partial_seed*.npz)")
 def _second_arms(recs):
     """{seed: (psnr_pre, {iteration: psnr}, psnr_end, threads)} of tests/golden/c2_reference_rerun.npz: the same seed through the reference's modules at
     another thread count (another summation order inside its GEMMs and nothing else) — the reference against itself at this size."""
@@ -108,6 +107,7 @@ def _second_arms(recs):
     return out
 
 
+@pytest.mark.skipif(not _records(), reason="no configs[1] reference record (tests/golden/c2_reference.npz)")
 def test_configs1_full_schedule_against_the_reference_modules():
     recs = _records()
     seeds = sorted(recs)

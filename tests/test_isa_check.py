@@ -22,11 +22,19 @@ def test_fragment_read_without_wait_is_caught():
     ok = ["ds_read_b128 a[0:3], v4 offset:512", "v_add_f32_e32 v1, v2, v3", "s_waitcnt lgkmcnt(0)", "v_mfma_f32_32x32x16_bf16 a[16:31], a[0:3], v[8:11], a[16:31]"]
     assert m.check_agpr_fragment_reads("k", ok) == 1
     bad = [ok[0], ok[1], ok[3]]
-    with pytest.raises(RuntimeError, match="no s_waitcnt lgkmcnt"):
+    with pytest.raises(RuntimeError, match="no s_waitcnt in between retires"):
         m.check_agpr_fragment_reads("k", bad)
     # a wait that only counts the vector-memory queue does not cover the LDS read
     with pytest.raises(RuntimeError):
         m.check_agpr_fragment_reads("k", [ok[0], "s_waitcnt vmcnt(0)", ok[3]])
+    # a COUNTED wait (hipcc's own, in the fp32 blocks) retires all but the N youngest LDS operations: the first of two reads is covered by lgkmcnt(1),
+    # the second is not; with a scalar load outstanding (out-of-order returns on the same counter) only lgkmcnt(0) counts
+    two = [ok[0], "ds_read_b128 a[4:7], v4 offset:1024", "s_waitcnt lgkmcnt(1)"]
+    assert m.check_agpr_fragment_reads("k", two + [ok[3]]) == 2
+    with pytest.raises(RuntimeError):
+        m.check_agpr_fragment_reads("k", two + ["v_mfma_f32_32x32x16_bf16 a[16:31], a[4:7], v[8:11], a[16:31]"])
+    with pytest.raises(RuntimeError):
+        m.check_agpr_fragment_reads("k", ["s_load_dwordx2 s[0:1], s[4:5], 0x0"] + two + [ok[3]])
     # an MFMA on other registers may issue while the read is in flight
     assert m.check_agpr_fragment_reads("k", [ok[0], "v_mfma_f32_32x32x16_bf16 a[16:31], a[4:7], v[8:11], a[16:31]", ok[2], ok[3]]) == 1
 
