@@ -517,8 +517,8 @@ class AtlasFit:
         self._chk(self.lib.af_debug_set_dw_cost(self.h, arr, float(seg_cost)))
 
     def set_mlp_mode(self, mode):
-        """Hidden-layer products of the MLP chains: 1 = bf16x6 on the bf16 matrix pipe (default), 0 = fp32 MFMA (cross-check),
-        2 = bf16x6 forward, three-product backward chain (experiment)."""
+        """Hidden-layer products of the MLP chains: 3 = f16x3 on the fp16 matrix pipe (default since round 6), 1 = bf16x6 on the bf16 matrix pipe,
+        0 = fp32 MFMA (cross-check), 2 = bf16x6 forward, three-product bf16 backward chain (experiment)."""
         self._chk(self.lib.af_set_mlp_mode(self.h, int(mode)))
         if hasattr(self, "arithmetic"):
             self.arithmetic["mlp_mode"] = int(mode)

@@ -105,9 +105,9 @@ struct af_handle {
   size_t total_params = 0, img_f_floats = 0, img_b_floats = 0, bias_floats = 0, sf_bytes = 0, sb_bytes = 0;
   char *img_sf = nullptr, *img_sb = nullptr;   // bf16x6 chain streams
   char *img_hf = nullptr, *img_hb = nullptr; size_t hf_bytes = 0, hb_bytes = 0;   // f16x3 chain streams (mlphf.hip)
-  int mlp_mode = 1;                            // MLP chains: 1 = hidden layers on the bf16 matrix pipe, fp32-faithful bf16x6 (mlpbf.hip); 0 = fp32 MFMA (mlp.hip);
-                                               // 2 = as 1 with the backward chain on three products (experiment);
-                                               // 3 = f16x3: two-term fp16 split with a scale per row, three products, both directions (mlphf.hip)
+  int mlp_mode = 3;                            // MLP chains: 3 = f16x3, the default since round 6: hidden layers on the fp16 matrix pipe, two-term fp16 split with a scale
+                                               // per row, three products, both directions (mlphf.hip); 1 = bf16x6 on the bf16 pipe (mlpbf.hip, the default of rounds 2-5);
+                                               // 2 = as 1 with the backward chain on three bf16 products (experiment); 0 = fp32 MFMA (mlp.hip)
   float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *pre_m = nullptr, *pre_v = nullptr, *grads = nullptr;
   float *img_f = nullptr, *img_b = nullptr, *bias_img = nullptr;
   long long adam_step = 0;

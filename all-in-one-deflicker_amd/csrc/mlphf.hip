@@ -135,16 +135,42 @@ AF_DEV void hf_sign_in(uint32_t& mk, float v) { uint32_t t; asm("v_sub_f32 %1, 0
 AF_DEV void hf_max3(float& m, float a, float b) { asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
 AF_DEV void hf_max3_abs(float& m, float a, float b) { asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b)); }
 
+// x if bit (31 - e) of the sign-mask word is set, else 0 (mlpbf.hip bf_mask_keep)
+template <int E> AF_DEV float hf_mask_keep(float x, uint32_t mk) {
+  uint32_t r;
+  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %0, %3" : "=&v"(r) : "v"(mk), "n"(31 - ((E >> 4) & 1) * 16 - (E & 15)), "v"(x));
+  return __builtin_bit_cast(float, r);
+}
+// ---- the element-wise tail of a layer, moved INTO the next layer's product (round 6) ------------------------------------------------
+// With three products a 256 -> 256 block is 12.3 k cycles of MFMA issue and the element-wise epilogue between two blocks (bias, ReLU, sign bits /
+// sign mask, the row maximum) ~2.5 k with nothing to hide behind.  Only two things are needed before the next block can start: the activations in
+// VGPRs and the row's scale.  So the exposed part is a PRE-PASS — accumulator -> register (+ bias in the forward chain) and the maximum — and every
+// element is FINISHED one k-step before it is split, in the shadow of that k-step's first eight MFMAs (one element per slot):
+//   FIN 1  forward, training: x = relu(z), its sign bit shifted into the mask word      FIN 2  forward, inference: x = relu(z)
+//   FIN 3  backward: x = (raw * invp) masked by the sign word (invp: what takes the previous block's accumulator back, a power of two)
+// The row maximum is taken over the UNFINISHED values: max(0, z) is the ReLU's maximum exactly; in the backward chain the unmasked maximum bounds
+// the masked one (a scale is only ever an upper bound: nothing overflows, and a row keeps its bits unless every large entry is masked out).
+struct HfFin { uint32_t mk[4]; float invp; };
+template <int FIN, int E> AF_DEV void hf_finish(float (&in)[128], HfFin& f) {
+  if constexpr (FIN == 1) { in[E] = af_relu(in[E]); hf_sign_in(f.mk[E >> 5], in[E]); }
+  else if constexpr (FIN == 2) in[E] = af_relu(in[E]);
+  else if constexpr (FIN == 3) in[E] = hf_mask_keep<E>(in[E] * f.invp, f.mk[E >> 5]);
+}
+template <int FIN, int E0, int... Es> AF_DEV void hf_finish_range(float (&in)[128], HfFin& f, std::integer_sequence<int, Es...>) {
+  (hf_finish<FIN, E0 + Es>(in, f), ...);
+}
+
 // ---- the three-product k-step as 24 hand-placed issue slots (the scheme of mlpbf.hip bf_slot) --------------------------------------
 //   MFMAs    0-7 W_l x B_h | [publish, k-steps with S % 4 == 3] | 8-15 W_h x B_l, 16-23 W_h x B_h       (accumulators start at 0: S == 0, slots 0-7 take C = 0)
 //   reads    W_h fragments two per slot in 0-3 (used from 8), the next k-step's W_l in 8-11 (of the chunk just published when S % 4 == 3)
 //   stores   (training chains) the eight registers 8S .. 8S+7 of the block's input, one per slot in 4-7 and 20-23
 //   DMA      pieces of the chunk behind the published one in slots 9, 11, 13, 15, 17 of k-steps S % 4 = 3, 0, 1 and slot 9 of S % 4 = 2:
 //            all sixteen are at least 23 MFMAs old at the next publish, and exactly AF_HF_KEEP = 8 stores are younger than the last
+//   finish   element 8(S+1) + I of the block's input in slot I < 8 (hf_finish: <= 3 VALU), i.e. before the split below reads it
 //   split    of the next k-step's B operand: one pair (4 VALU) in each of slots 12, 14, 16, 18
-template <int S, bool STORES, int I>
-AF_DEV void hf_slot(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& pp, f32x4 (&fh)[8], f32x4 (&fln)[8], HfB& bn,
-                    uint32_t la, uint32_t nla, HfStream& cs, const TileStore& ts) {
+template <int S, bool STORES, int FIN, int I>
+AF_DEV void hf_slot(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, f32x4 (&fh)[8], f32x4 (&fln)[8], HfB& bn,
+                    uint32_t la, uint32_t nla, HfStream& cs, const TileStore& ts, HfFin& fin) {
   constexpr int sl = S & 3, T = I & 7;
   constexpr bool NEXT = S != 15;
   if constexpr (I == 0 || I == 8) hf_lds_wait();          // the fragments of this slot group have landed (read >= 4 MFMAs ago)
@@ -177,6 +203,8 @@ AF_DEV void hf_slot(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& 
       af_bs32(in[8 * S + r8], ts.r, ts.voff + (rr & 3) * 128, (32 * (S >> 1) + 8 * (rr >> 2)) * 128);
     }
   }
+  // ---- finish one element of the next k-step's operand
+  if constexpr (FIN != 0 && S + 1 < 16 && I < 8) hf_finish<FIN, 8 * (S + 1) + I>(in, fin);
   // ---- split of the next k-step's B operand
   if constexpr (S + 1 < 16 && (I == 12 || I == 14 || I == 16 || I == 18)) {
     constexpr int i = (I - 12) / 2;
@@ -186,18 +214,18 @@ AF_DEV void hf_slot(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& 
   }
   __builtin_amdgcn_sched_barrier(0);
 }
-template <int S, bool STORES, int... I0, int... I1>
-AF_DEV void hf_kstep(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts,
+template <int S, bool STORES, int FIN, int... I0, int... I1>
+AF_DEV void hf_kstep(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts, HfFin& fin,
                      std::integer_sequence<int, I0...>, std::integer_sequence<int, I1...>) {
   f32x4 fh[8], fln[8];
   HfB bn = pp.b;
   const char* nxt_lane = lane_base;
   __builtin_amdgcn_sched_barrier(0);
   const uint32_t la = (uint32_t)(size_t)lane_base;
-  (hf_slot<S, STORES, I0>(acc, in, sc, pp, fh, fln, bn, la, la, cs, ts), ...);                                     // slots 0..7
+  (hf_slot<S, STORES, FIN, I0>(acc, in, sc, pp, fh, fln, bn, la, la, cs, ts, fin), ...);                           // slots 0..7
   if constexpr ((S & 3) == 3) nxt_lane = cs.template publish<(STORES ? AF_HF_KEEP : 0)>(S == 15 ? after_bytes : AF_SLOT_HF) + lane_off;
   const uint32_t nla = (uint32_t)(size_t)nxt_lane;
-  (hf_slot<S, STORES, 8 + I1>(acc, in, sc, pp, fh, fln, bn, la, nla, cs, ts), ...);                                // slots 8..23
+  (hf_slot<S, STORES, FIN, 8 + I1>(acc, in, sc, pp, fh, fln, bn, la, nla, cs, ts, fin), ...);                      // slots 8..23
   hf_lds_wait();          // the next k-step's W_l fragments (read in slots 8..11) before anything - a register copy included - touches them
 #pragma unroll
   for (int T = 0; T < 8; ++T) pp.fl[T] = fln[T];
@@ -207,19 +235,21 @@ AF_DEV void hf_kstep(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe&
 // A whole 256 -> 256 product (16 k-steps = 4 chunks), accumulators starting at zero.  On entry the first chunk is published at
 // lane_base (hf_enter has fetched its first fragments); on exit lane_base addresses the published chunk behind the block
 // (after_bytes long).
-template <bool STORES, int... Ss>
-AF_DEV void hf_block_impl(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts,
+template <bool STORES, int FIN, int... Ss>
+AF_DEV void hf_block_impl(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts, HfFin& fin,
                           std::integer_sequence<int, Ss...>) {
-  (hf_kstep<Ss, STORES>(acc, in, sc, pp, lane_base, cs, lane_off, after_bytes, ts, std::make_integer_sequence<int, 8>{}, std::make_integer_sequence<int, 16>{}), ...);
+  (hf_kstep<Ss, STORES, FIN>(acc, in, sc, pp, lane_base, cs, lane_off, after_bytes, ts, fin, std::make_integer_sequence<int, 8>{}, std::make_integer_sequence<int, 16>{}), ...);
 }
-template <bool STORES>
-AF_DEV void hf_block(f32x16 (&acc)[8], const float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts) {
-  hf_block_impl<STORES>(acc, in, sc, pp, lane_base, cs, lane_off, after_bytes, ts, std::make_integer_sequence<int, 16>{});
+template <bool STORES, int FIN>
+AF_DEV void hf_block(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, const char*& lane_base, HfStream& cs, int lane_off, int after_bytes, const TileStore& ts, HfFin& fin) {
+  hf_block_impl<STORES, FIN>(acc, in, sc, pp, lane_base, cs, lane_off, after_bytes, ts, fin, std::make_integer_sequence<int, 16>{});
 }
-// entering a block: the lo-level fragments and the split B operand of its first k-step
-AF_DEV void hf_enter(HfPipe& pp, const float (&in)[128], float sc, const char* lane_base) {
+// entering a block: the lo-level fragments of its first k-step, the first eight elements of its input finished and split
+template <int FIN>
+AF_DEV void hf_enter(HfPipe& pp, float (&in)[128], float sc, const char* lane_base, HfFin& fin) {
 #pragma unroll
   for (int T = 0; T < 8; ++T) pp.fl[T] = *(const f32x4*)(lane_base + (T * 2 + 1) * 1024);     // compiler-visible reads
+  hf_finish_range<FIN, 0>(in, fin, std::make_integer_sequence<int, 8>{});
   pp.b = hf_split_in(in, 0, sc);
 }
 
@@ -302,11 +332,15 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   HfPipe pp;
   float sc = 1.f, inv = 1.f;
 
-  // acc -> in[] = relu(Z_l) = X_{l+1} (its stores are deferred), the sign bits, and the row's scale for the next block.
-  // SCALED: acc holds 2^12 sc Z without the bias (a hidden block); else Z itself (layer 0: bias-initialised fp32 block).
-  auto relu_out = [&](int l, auto scaled) {
+  // The PRE-PASS of layer l's tail: acc -> in[] = Z_l (SCALED: acc holds 2^12 sc Z without the bias, a hidden block; else Z itself, the
+  // bias-initialised fp32 layer 0), the row maximum of relu(Z_l) and from it the next block's scale.  X_{l+1} = relu(Z_l) and its sign bits are
+  // finished element by element inside the next block (hf_finish), or by finish_all() in front of the output layer.
+  constexpr int FIN = TRAIN ? 1 : 2;
+  HfFin fin; fin.invp = 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fin.mk[i] = 0u;
+  auto pre_out = [&](int l, auto scaled) {
     constexpr bool SCALED = decltype(scaled)::value;
-    uint32_t mk[4] = {0u, 0u, 0u, 0u};
     float mx = 0.f;
     // the bias quad of the NEXT four features is fetched while a quad is processed, each feature tile fenced: left to the scheduler all 32 reads
     // of a layer are hoisted to the top (128 live registers, a spilled chain)
@@ -323,25 +357,27 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
           const int r = q * 4 + p;
           float z = acc[T][r];
           if constexpr (SCALED) z = __builtin_fmaf(z, inv, bq[p]);
-          const float v = af_relu(z);
-          in[T * 16 + r] = v;
-          if (TRAIN) hf_sign_in(mk[T >> 1], v);
+          in[T * 16 + r] = z;
         }
         hf_max3(mx, in[T * 16 + q * 4], in[T * 16 + q * 4 + 1]);
         hf_max3(mx, in[T * 16 + q * 4 + 2], in[T * 16 + q * 4 + 3]);
         bq = bnx;
       }
-      __builtin_amdgcn_sched_barrier(0);      // (TRAIN: also keeps the 128 sign tests from being batched ahead of their use)
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (TRAIN) ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+    hf_row_scale(mx, sc, inv);
+  };
+  // the sign bits of X_{l+1} = relu(Z_l), complete once the block that consumes X_{l+1} (or finish_all) has finished every element
+  auto store_masks = [&](int l) {
     if constexpr (TRAIN) {
       if (live) {
-        u32x4 m4 = {mk[0], mk[1], mk[2], mk[3]};
+        u32x4 m4 = {fin.mk[0], fin.mk[1], fin.mk[2], fin.mk[3]};
         *(u32x4*)(a.masks + (((size_t)l * a.nt_stride + tile) * 64 + lane) * 4) = m4;
       }
-      ts.r = af_rsrc_uniform(a.acts + ((size_t)l * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fin.mk[i] = 0u;
     }
-    hf_row_scale(mx, sc, inv);
-    AF_ELEMWISE_FENCE();      // asm element-wise ops never next to an MFMA that reads them (mlpbf.hip relu_out; isa_check.py rule (d))
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
 
@@ -352,7 +388,7 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   init_bias(acc, bias_lds, 0, h);
   mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
   HF_MARK(3);
-  relu_out(0, std::false_type{});
+  pre_out(0, std::false_type{});
   HF_MARK(4);
   const char* lane_base = cs.publish(nl > 2 ? CB::HID : CB::last_bytes(nl)) + lane_off;     // what lies behind layer 0: the first hidden chunk, or the output layer
   cs.lead5();
@@ -363,10 +399,11 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   int l = 1;
 #pragma unroll 1
   do {
-    hf_enter(pp, in, sc, lane_base);
+    hf_enter<FIN>(pp, in, sc, lane_base, fin);
     const bool skip = NS::SKIP != 0 && ((NS::SKIP >> l) & 1);
     const int behind = l == nl - 2 ? CB::last_bytes(nl) : CB::HID;
-    hf_block<(TRAIN && !(AF_ABL & 1))>(acc, in, sc, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, ts);
+    hf_block<(TRAIN && !(AF_ABL & 1)), FIN>(acc, in, sc, pp, lane_base, cs, lane_off, skip ? CB::SKIP : behind, ts, fin);
+    store_masks(l - 1);
     if constexpr (NS::SKIP != 0) {
       if (skip) {      // the PE columns of a skip layer on the fp32 pipe, into the SAME (scaled) accumulators: B = 2^12 sc pe
         // scaled in place and back (powers of two, |pe| <= 1: exact both ways) - a second copy of the 20 features does not fit the register file
@@ -381,11 +418,15 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
       }
     }
     HF_MARK(4 + 2 * l);
-    relu_out(l, std::true_type{});
+    pre_out(l, std::true_type{});
     HF_MARK(5 + 2 * l);
   } while (++l <= nl - 2);
   }
   lane_base -= lane_off;
+  // the last hidden layer's output has no block behind it: finished here, in front of the output layer
+  hf_finish_range<FIN, 0>(in, fin, std::make_integer_sequence<int, 128>{});
+  store_masks(nl - 2);
+  AF_ELEMWISE_FENCE();      // asm element-wise ops never next to an MFMA that reads them (mlpbf.hip relu_out; isa_check.py rule (d))
 
   // ---- output layer (1..3 real outputs), tanh, on 4x4x1 fp32 MFMA blocks (see mlp.hip); lane_base = the chunk's LDS base
   {
@@ -427,15 +468,6 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   HF_MARK(30);
 }
 
-// x if bit (31 - e) of the sign-mask word is set, else 0 (mlpbf.hip bf_mask_keep)
-template <int E> AF_DEV float hf_mask_keep(float x, uint32_t mk) {
-  uint32_t r;
-  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %0, %3" : "=&v"(r) : "v"(mk), "n"(31 - ((E >> 4) & 1) * 16 - (E & 15)), "v"(x));
-  return __builtin_bit_cast(float, r);
-}
-template <bool SCALED, int... Es> AF_DEV void hf_mask_all(float (&in)[128], const f32x16 (&acc)[8], const uint32_t (&mk)[4], float inv, std::integer_sequence<int, Es...>) {
-  ((in[Es] = hf_mask_keep<Es>(SCALED ? acc[Es >> 4][Es & 15] * inv : acc[Es >> 4][Es & 15], mk[Es >> 5])), ...);
-}
 template <int... Ps> AF_DEV float hf_absmax(const float (&in)[128], std::integer_sequence<int, Ps...>) {
   float mx = 0.f;
   (hf_max3_abs(mx, in[2 * Ps], in[2 * Ps + 1]), ...);
@@ -482,15 +514,21 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
   HfPipe pp;
   float sc = 1.f, inv = 1.f;
 
-  // acc = dX_l (SCALED: times 2^12 sc); mask with the sign bits of X_l (masks[l-1]) -> in[] = dZ_{l-1}, and that row's scale
-  auto mask_out = [&](int l, auto scaled) {
+  // The PRE-PASS of a block's tail: acc = dX_l (SCALED: times 2^12 sc) -> in[] raw, the sign words of X_l (masks[l-1]) and what takes the raw values
+  // back (fin.invp), the row maximum of the unmasked values and from it the next block's scale.  dZ_{l-1} = (raw invp) . relu'(Z_{l-1}) is finished
+  // element by element inside the next block (hf_finish<3>), or by the finish in front of the layer-0 stage.
+  HfFin fin; fin.invp = 1.f;
+  auto pre_mask = [&](int l, auto scaled) {
     const u32x4 m4 = *(const u32x4*)(a.masks + (((size_t)(l - 1) * a.nt_stride + tile) * 64 + lane) * 4);
-    const uint32_t mk[4] = {m4[0], m4[1], m4[2], m4[3]};
-    hf_mask_all<decltype(scaled)::value>(in, acc, mk, inv, std::make_integer_sequence<int, 128>{});
+    fin.mk[0] = m4[0]; fin.mk[1] = m4[1]; fin.mk[2] = m4[2]; fin.mk[3] = m4[3];
+    fin.invp = decltype(scaled)::value ? inv : 1.f;
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) in[T * 16 + r] = acc[T][r];
     const float mx = hf_absmax(in, std::make_integer_sequence<int, 64>{});
     ts.r = af_rsrc_uniform(a.dz + ((size_t)(l - 1) * a.nt_stride + tile) * AF_TILE_F, live ? AF_TILE_F * 4 : 0);
-    hf_row_scale(mx, sc, inv);
-    AF_ELEMWISE_FENCE();
+    hf_row_scale(mx * fin.invp, sc, inv);
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
@@ -501,7 +539,7 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
   HF_MARK(2);
   mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
   HF_MARK(3);
-  mask_out(nl - 1, std::false_type{});
+  pre_mask(nl - 1, std::false_type{});
   HF_MARK(4);
   const char* lane_base = cs.publish(nl > 2 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096)) + lane_off;
   cs.lead5();
@@ -509,14 +547,17 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
 
 #pragma unroll 1
   for (int l = nl - 2; l >= 1; --l) {
-    hf_enter(pp, in, sc, lane_base);
+    hf_enter<3>(pp, in, sc, lane_base, fin);
     // behind the last hidden block: the atlas net's layer-0 block (first half), or nothing (a harmless stage of the padding)
-    hf_block<!(AF_ABL & 1)>(acc, in, sc, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), ts);
+    hf_block<!(AF_ABL & 1), 3>(acc, in, sc, pp, lane_base, cs, lane_off, l > 1 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096), ts, fin);
     HF_MARK(4 + 2 * (nl - 1 - l));
-    mask_out(l, std::true_type{});
+    pre_mask(l, std::true_type{});
     HF_MARK(5 + 2 * (nl - 1 - l));
   }
   lane_base -= lane_off;
+  // dZ_0 has no block behind it on this pipe: finished here
+  hf_finish_range<3, 0>(in, fin, std::make_integer_sequence<int, 128>{});
+  AF_ELEMWISE_FENCE();      // asm element-wise ops never next to an MFMA that reads them (isa_check.py rule (d))
 
   if constexpr (NS::DX0) {
     // dPE = W_0^T dZ_0  (M = 64 padded PE features, K = 256) in two 16-group halves, then through sin/cos to the 2-D input

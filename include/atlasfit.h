@@ -172,12 +172,14 @@ int af_set_dw_mode(af_handle* h, int mode);
  * partition of the row batch over workgroups = another summation ORDER of the same partial products, nothing else; results stay
  * bit-reproducible for a given row.  AF_EINVAL (handle unchanged) for a row that is not valid or cannot be scheduled. */
 int af_debug_set_dw_cost(af_handle* h, const double* cost5, double seg_cost);
-/* The same choice for the 256x256 hidden-layer products of the forward / backward chains (mlpbf.hip vs mlp.hip): 1 (default)
- * = bf16x6, 0 = fp32 matrix pipe, 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16
- * operands — a measured experiment, not a default.  3 = "f16x3" (mlphf.hip, round 6): every operand as two fp16 terms of its scaled
- * value, three products on v_mfma_f32_32x32x16_f16, a power-of-two scale per ROW and layer on the activations / gradients and a fixed 2^12 on the
- * weights; af_train_steps / af_pretrain return AF_ERANGE once a hidden-layer weight reaches |w| >= 8 (the images stay finite up to 16).
- * (Python mirror: AtlasFit(cfg, experiment_env=True) maps AF_MLP_MODE=<m>, AF_MLP_FP32=1 selects 0.)
+/* The same choice for the 256x256 hidden-layer products of the forward / backward chains: 3 (default since round 6) = "f16x3" (mlphf.hip): every
+ * operand as two fp16 terms of its scaled value, three products on v_mfma_f32_32x32x16_f16, a power-of-two scale per ROW and layer on the activations /
+ * gradients and a fixed 2^12 on the weights — measured from the kernels' own tiles, its per-layer error against fp64 is below an fp32 fmaf chain's
+ * (tests/test_gpu_gemm_error.py); af_train_steps / af_pretrain return AF_ERANGE once a hidden-layer weight reaches |w| >= 8 (the images stay finite up
+ * to 16; mode 1 has no such limit).  1 = bf16x6 (mlpbf.hip: three bf16 terms, six products; the default of rounds 2-5), 0 = fp32 matrix pipe (mlp.hip),
+ * 2 = bf16x6 forward with the backward chain (dX = W^T dZ) on three products of two-bf16 operands — a measured experiment, narrower than fp32.
+ * k_adam maintains the 16-bit weight streams of the mode in force only; a switch between the stream families re-emits them (synchronises the stream).
+ * (Python mirror: AF_EXPERIMENT=1 AF_MLP_MODE=<m> maps onto this call; AF_MLP_FP32=1 selects 0.)
  * pre_train_mapping's MLP chains always run the fp32 16-row kernels (mlp16.hip); its weight-gradient GEMM follows af_set_dw_mode. */
 int af_set_mlp_mode(af_handle* h, int mode);
 /* The arithmetic modes in force (either pointer may be NULL): what the host side records next to its results. */

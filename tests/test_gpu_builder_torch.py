@@ -5,8 +5,9 @@ geometry:
 
   * cv2.resize(..., INTER_LINEAR) samples at the half-pixel centres src = (dst + 0.5) * scale - 0.5 with the edge clamped —
     exactly torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=False).  Evaluated in fp64 it is the exact
-    bilinear value; OpenCV (and this kernel) round the two interpolation coefficients to float32 first, so the results agree to ~1e-6 of
-    the value range, not bit for bit.
+    bilinear value; OpenCV (and this kernel) form the source coordinate in float32 — `fx = (float)((dx + 0.5) * scale - 0.5); fx -= sx` —
+    so a coefficient carries the rounding of a coordinate of magnitude ~W (6e-8 W), times the difference of the two taps: agreement to
+    ~1e-7 x W x (value spread), not bit for bit (exact for the integer scale factors of the shipped --down 4, where the coefficients are 0.5).
   * cv2.remap(flow21, flow12 + grid, INTER_LINEAR) with the default constant-0 border is
     grid_sample(mode="bilinear", padding_mode="zeros", align_corners=True) on pixel coordinates — up to cv2's quantisation of the
     sampling position to 1/32 px (INTER_BITS = 5), which moves a sampled flow by at most (1/64 px) x its local gradient.  The consistency
@@ -40,8 +41,10 @@ def test_resize_against_torch_interpolate(src_hw, dst_hw, u8):
     err = (dst.double() - ref).abs().max().item()
     span = float(ref_in.abs().max())
     print("resize %s -> %s %s: max |kernel - torch fp64 interpolate| = %.3g (value range %.3g)" % (src_hw, dst_hw, "uint8" if u8 else "float32", err, span))
-    # float32 coefficients (|da| <= 6e-8 each) on values up to `span`, one float32 rounding of the result
-    assert err <= 4e-7 * max(span, 1.0), err
+    # a float32 coordinate of magnitude <= max(sh, sw) (half an ulp each for the product and the subtraction) times the spread of two taps (<= 2 span),
+    # plus one float32 rounding of the result.  A wrong half-pixel convention, a transposed axis or a clamped edge would be O(span).
+    tol = 1.5e-7 * max(sh, sw) * 2.0 * max(span, 1.0) + 2e-7 * max(span, 1.0)
+    assert err <= tol, (err, tol)
 
 
 @pytest.mark.parametrize("hw", [(90, 160), (432, 768)])
