@@ -138,6 +138,15 @@ AF_DEV f32x4 af_bl128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 AF_DEV void af_bs32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
 }
+// the chains' tile stores (activations / gradients written once, read once by k_dw, 1.3 GB per step: nothing to keep in a cache): cache-policy bits
+// of the store (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1).  Measured per 128-row task in core ticks (tools/hfbench.hip, profiles/r6_hfbench_tile_store_policy.txt):
+// nt -2.9 % (mapping forward) / -3.6 % (mapping backward) / -1..2 % (atlas) against the default policy; sc1, sc0 sc1, nt sc1: -1.5 %.
+#ifndef AF_TILE_AUX
+#define AF_TILE_AUX 2
+#endif
+AF_DEV void af_bs32_tile(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, AF_TILE_AUX);
+}
 AF_DEV void af_bs128(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }

@@ -21,6 +21,20 @@
 // one ds_read_b128.  db falls out of the A fragments for free.
 #include <utility>
 #include "af_dev.h"
+// The operand tiles are read once per step (1.3 GB, written by the chains with nt stores) and the partial blocks are written once and read once by
+// k_adam: the non-temporal policy on both (gfx940+ nt bit) is an experiment switch measured on the real step (tools/experiments/README.md).
+#ifndef DW_LOAD_NT
+#define DW_LOAD_NT 0
+#endif
+#ifndef DW_STORE_NT
+#define DW_STORE_NT 1
+#endif
+AF_DEV void dw_glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, DW_LOAD_NT ? 2 : 0);
+}
+AF_DEV void dw_bs32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, DW_STORE_NT ? 2 : 0);
+}
 
 #ifndef DW_ABL
 #define DW_ABL 0     // tools/dwbench.hip timing ablations of k_dw_bf: bit0 no operand split (raw bits fed to the MFMAs), bit1 one MFMA per
@@ -81,7 +95,7 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
   auto issue = [&](int s, int k) {                       // piece k of stage s -> ring slot s & 3
     const int sc = s < S ? s : S - 1;                    // past the end: harmless re-stage (keeps the vmcnt arithmetic uniform)
     const char* g = src[k] + (size_t)(sg.t0 + (sc >> 1)) * tstr[k] + (sc & 1) * 64;
-    af_glds16(g, smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
+    dw_glds16(g, smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
   };
 #pragma unroll
   for (int s = 0; s < DW_STAGES - 1; ++s)
@@ -152,12 +166,12 @@ AF_DEV void dw_segment(const DwJob& jb, const DwSeg& sg, float* partial, char* s
       for (int y = 0; y < TIW; ++y)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          af_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
+          dw_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
   }
 #pragma unroll
   for (int x = 0; x < TOW; ++x) {
     const float tot = dbacc[x] + __shfl_xor(dbacc[x], 32);
-    if (store_db && h == 0) af_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
+    if (store_db && h == 0) dw_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
   }
 }
 
@@ -286,7 +300,11 @@ struct Dw88 {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 template <int IMM> AF_DEV void dw_glds_s(uint32_t voff, const char* sbase, uint32_t lds) {
+#if DW_LOAD_NT
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory", "scc", "m0");
+#else
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory", "scc", "m0");
+#endif
 }
 #pragma clang diagnostic pop
 template <int CUR, int Y, int I>
@@ -451,11 +469,11 @@ AF_DEV void dw_segment_88(const DwJob& jb, const DwSeg& sg, float* partial, char
     for (int y = 0; y < 4; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        af_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
+        dw_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     const float tot = q.db[x] + __shfl_xor(q.db[x], 32);
-    if (store_db && h == 0) af_bs32(tot, rblk, (8 * 32 * pld + a0 * 32 + m) * 4, x * 128);
+    if (store_db && h == 0) dw_bs32(tot, rblk, (8 * 32 * pld + a0 * 32 + m) * 4, x * 128);
   }
 }
 
@@ -508,7 +526,7 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
     const char* gb = sgpr((const char*)jb.B + t * jb.b_stride * 4u + (sc & 1) * 64);
     const bool all_a = (k + 1) * 256 <= TO * 128, all_b = k * 256 >= TO * 128 && (k + 1) * 256 <= NP;
     const char* g = all_a ? ga : (all_b ? gb : (sel_a[k] ? ga : gb));
-    af_glds16(g + soff[k], smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
+    dw_glds16(g + soff[k], smem + (s % DW_STAGES) * SLOT + k * 4096 + wave * 1024);
   };
 #pragma unroll
   for (int s = 0; s < DW_STAGES - 1; ++s)
@@ -684,12 +702,12 @@ AF_DEV void dw_segment_bf(const DwJob& jb, const DwSeg& sg, float* partial, char
       for (int y = 0; y < TIW; ++y)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          af_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
+          dw_bs32(acc[x][y][r], rblk, voff, ((x * 32 + (r & 3) + 8 * (r >> 2)) * pld + y * 32) * 4);
   }
 #pragma unroll
   for (int x = 0; x < TOW; ++x) {
     const float tot = dbacc[x] + __shfl_xor(dbacc[x], 32);
-    if (store_db && h == 0) af_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
+    if (store_db && h == 0) dw_bs32(tot, rblk, (TO * 32 * pld + a0 * 32 + m) * 4, x * 128);
   }
 }
 

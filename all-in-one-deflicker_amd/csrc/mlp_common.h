@@ -194,7 +194,7 @@ template <int T>
 AF_DEV void store_tile_part(const float (&v)[128], __amdgpu_buffer_rsrc_t r, int voff) {
   // the 128-B steps between p = 0..3 ride in the instruction's immediate offset: one soffset per (T, q)
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) af_bs32(v[T * 16 + rr], r, voff + (rr & 3) * 128, (32 * T + 8 * (rr >> 2)) * 128);
+  for (int rr = 0; rr < 16; ++rr) af_bs32_tile(v[T * 16 + rr], r, voff + (rr & 3) * 128, (32 * T + 8 * (rr >> 2)) * 128);
 }
 
 // Deferred stores of one 32x256 block: one feature tile per k-group of the following GEMM block.

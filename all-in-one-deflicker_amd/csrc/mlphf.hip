@@ -77,8 +77,10 @@ struct HfStream {
   template <int KEEP = 0>
   AF_DEV const char* publish(int BYTES) {
     if constexpr (KEEP == 0) { while (p_it < NI) issue1(); }
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KEEP) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(AF_ABL & 4)) {          // (timing probe: no wait, no barrier)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KEEP) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     asm volatile("" ::: "memory");
     const char* cur = smem + (stg & 1) * AF_SLOT_HF;
     src += BYTES; ++stg;
@@ -200,7 +202,7 @@ AF_DEV void hf_slot(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, f3
     constexpr int r8 = (I >= 4 && I < 8) ? I - 4 : (I >= 20 ? 4 + I - 20 : -1);
     if constexpr (r8 >= 0) {
       constexpr int rr = 8 * (S & 1) + r8;
-      af_bs32(in[8 * S + r8], ts.r, ts.voff + (rr & 3) * 128, (32 * (S >> 1) + 8 * (rr >> 2)) * 128);
+      af_bs32_tile(in[8 * S + r8], ts.r, ts.voff + (rr & 3) * 128, (32 * (S >> 1) + 8 * (rr >> 2)) * 128);
     }
   }
   // ---- finish one element of the next k-step's operand

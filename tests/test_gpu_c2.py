@@ -1,21 +1,23 @@
-"""BASELINE configs[1] — the headline config — end to end against the REFERENCE's own modules (VERDICT round 4, item 1): 80 frames
-768x432, pre_train_mapping 100 x F = 8000 steps, iters_num 10001 of the shipped config (config_flow_100.json:6,44), i.e. 5001
-iterations with the global-rigidity rows and 5000 without them (stage1_neural_atlas.py:151-231,246-251).
+"""BASELINE configs[1] — the headline config — end to end against the REFERENCE's own modules (VERDICT round 4 item 1, round 5 item 2): 80 frames
+768x432, pre_train_mapping 100 x F = 8000 steps, iters_num 10001 of the shipped config (config_flow_100.json:6,44), i.e. 5001 iterations with
+the global-rigidity rows and 5000 without them (stage1_neural_atlas.py:151-231,246-251).
 
-tests/golden/c2_reference.npz is written by `oracle/make_golden_c1.py --resx 768 --resy 432 --iters 10001 --log-every 250 --psnr-at 5000`
-in the build container (the reference's IMLP / loss functions / pre_train_mapping / torch.optim.Adam, ~6 h of CPU per seed on two
-threads): per seed the PSNR after the pre-train, after 5000 iterations, at the end, and the six loss terms every 250 iterations.
-Seeds 0 and 2 run on the translating video, seed 1 on the video whose flow differs at every pixel of every frame (holed masks).
-While a reference run is still going its `--partial` file (tests/golden/c2_partial_seed<k>.npz: the curve and PSNRs so far) is
-accepted in place of the complete record and everything it already holds is compared.
+tests/golden/c2_reference.npz is written by `oracle/make_golden_c1.py --resx 768 --resy 432 --iters 10001 --log-every 250 --psnr-at 5000` in the
+build container (the reference's IMLP / loss functions / pre_train_mapping / torch.optim.Adam; 3-8 CPU-hours per run): per seed the PSNR after
+the pre-train, after 5000 iterations and at the end, and the six loss terms every 250 iterations.  Even seeds run on the translating video, odd
+ones on the video whose flow differs at every pixel of every frame (holed masks).  tests/golden/c2_reference_rerun.npz holds SECOND arms of the
+same seeds at another thread count (another summation order inside the reference's GEMMs and nothing else): the reference against itself, which
+gives its run-to-run sigma at this size from its own pairs.
 
-Every random draw of the reference run came from torch's global CPU generator in the reference's order and is replayed here from
-the seed alone (as in test_gpu_c1.py).  The two fp32 trajectories decorrelate over 18 000 Adam steps; what must agree is where they
-pass and where they end.  No second reference arm exists at this size (6 h each), so the run-to-run sigma the tolerances need is
-measured on THIS side — every seed is run on three split-K partitions of the weight-gradient GEMM (af_debug_set_dw_cost: another
-summation order, nothing else) — and assumed for the reference as well (at configs[0] the reference's sigma was measured: 0.23 dB
-against this path's 0.2-0.3 dB; at configs[4] 0.22 against 0.37 dB).  BASELINE.md's 0.1 dB is asserted on top of two standard
-errors built from that sigma, per seed and on the mean over seeds, and the signed paired differences are printed with their SE."""
+Every random draw of a reference run came from torch's global CPU generator in the reference's order and is replayed here from the seed alone
+(as in test_gpu_c1.py).  The two fp32 trajectories decorrelate over 18 000 Adam steps; what must agree is where they pass and where they end:
+the paired difference hip - reference (against the mean of a seed's arms) over the seeds, with its standard error from the seeds' own spread.
+BASELINE.md's 0.1 dB is asserted on the mean on top of two standard errors, AND THE STANDARD ERROR ITSELF IS BOUNDED (a comparison that cannot
+resolve 0.1 dB must not pass as one that did), at the end and at the global-rigidity switch.
+
+GPU time (the driver's suite has 1200 s): one run per seed on the shipped split-K partition here; AF_C2_ALL_PARTITIONS=1 adds two more partitions
+per seed (another summation order on THIS side: its own run-to-run sigma, printed and used for the per-seed tolerance) — the builder's own gpurun
+executes that variant, its log is profiles/r6_pytest_c2_all_partitions.log and its pooled sigma is SIGMA_HIP_RECORDED below."""
 import glob
 import os
 
@@ -26,7 +28,10 @@ import torch
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 COMPLETE = os.path.join(GOLD, "c2_reference.npz")
-PARTITIONS = (None, "306,150,126,129,87", "306,170,145,148,100")
+ALL_PARTITIONS = (None, "306,150,126,129,87", "306,170,145,148,100")
+PARTITIONS = ALL_PARTITIONS if os.environ.get("AF_C2_ALL_PARTITIONS") else ALL_PARTITIONS[:1]
+SIGMA_HIP_RECORDED = 0.13          # dB: pooled run-to-run sigma of this path over the three partitions, seeds 0 1 2 4 (profiles/r6_pytest_c2_all_partitions.log)
+SE_MAX = 0.04                      # dB: the largest standard error of the mean paired difference under which "within 0.1 dB" is a resolved statement
 TERMS = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
 
 
@@ -41,13 +46,6 @@ def _records():
                                 curve=g["curves"][k], every=int(g["log_every"]), iters=int(g["iters"]), resx=int(g["resx"]), resy=int(g["resy"]),
                                 nframes=int(g["nframes"]), checksum=float(g["video_checksum"][k]), cpu_seconds=g["cpu_seconds"][k],
                                 threads=int(g["threads_per_seed"][k]) if "threads_per_seed" in g else -1)
-    for f in sorted(glob.glob(os.path.join(GOLD, "c2_partial_seed*.npz"))):
-        p = dict(np.load(f)); s = int(p["seed"])
-        if s in recs:
-            continue
-        recs[s] = dict(flow=str(p["flow_kind"]), psnr_pre=float(p["psnr_pre"]), psnr_at={int(i): float(v) for i, v in zip(p["psnr_at_iter"], p["psnr_at"])},
-                       psnr_end=None, curve=p["curve"], every=int(p["log_every"]), iters=int(p["iters"]), resx=int(p["resx"]), resy=int(p["resy"]),
-                       nframes=int(p["nframes"]), checksum=None, cpu_seconds=p["cpu_seconds"])
     return recs
 
 
@@ -112,88 +110,73 @@ def test_configs1_full_schedule_against_the_reference_modules():
     recs = _records()
     seeds = sorted(recs)
     arms2 = _second_arms(recs)
-    d_pre, d_mid, d_end, sig = [], [], [], []
+    npart = len(PARTITIONS)
+    d_pre, d_mid, d_end, narm, sig = [], [], [], [], []
     for seed in seeds:
         rec = recs[seed]
         every, n_logged = rec["every"], len(rec["curve"])
-        complete = rec["psnr_end"] is not None
-        upto = rec["iters"] if complete else (n_logged - 1) * every + 1         # a partial record: as far as its curve goes
         video = _video(seed, rec)
-        runs = [_run(seed, rec, part, upto, video) for part in PARTITIONS]
+        runs = [_run(seed, rec, part, rec["iters"], video) for part in PARTITIONS]
         del video
         p_pre = np.array([r[0] for r in runs])
-        print("seed %d (%s flow, %s, reference CPU time %.0f s pre-train + %.0f s loop): PSNR after the pre-train hip %s / reference %.4f dB"
-              % (seed, rec["flow"], "complete" if complete else "partial: %d of %d iterations" % (upto, rec["iters"]), rec["cpu_seconds"][0], rec["cpu_seconds"][1],
-                 np.array2string(p_pre, precision=4), rec["psnr_pre"]))
+        pre_refs = [rec["psnr_pre"]] + ([arms2[seed][0]] if seed in arms2 else [])
+        print("seed %d (%s flow, reference CPU time %.0f s pre-train + %.0f s loop, %d thread(s)%s): PSNR after the pre-train hip %s / reference %s dB"
+              % (seed, rec["flow"], rec["cpu_seconds"][0], rec["cpu_seconds"][1], rec["threads"], "; second arm: %d" % arms2[seed][3] if seed in arms2 else "",
+                 np.array2string(p_pre, precision=4), np.round(pre_refs, 4)))
         # 8000 pre-train steps on the same draws: the pre-train loss has ONE minimum (uv = 0.8 xy), both sides orbit it — and where on the orbit
         # step 8000 falls moves the PSNR of the (still random) atlas by up to 0.09 dB between this path's OWN partitions (seed 1: 16.856 .. 16.946)
-        sd_pre = max(float(p_pre.std(ddof=1)), 0.03)
-        assert abs(float(p_pre.mean()) - rec["psnr_pre"]) <= 0.1 + 2.0 * sd_pre * np.sqrt(1.0 + 1.0 / len(PARTITIONS)), (p_pre, rec["psnr_pre"])
-        d_pre.append((float(p_pre.mean() - rec["psnr_pre"]), 1))
+        assert abs(float(p_pre.mean()) - float(np.mean(pre_refs))) <= 0.1 + 2.0 * 0.05 * np.sqrt(1.0 / len(pre_refs) + 1.0 / npart), (p_pre, pre_refs)
+        d_pre.append(float(p_pre.mean() - np.mean(pre_refs)))
         curve = np.stack([r[3][::every][:n_logged, :6] for r in runs])          # (partition, logged iteration, term)
         ref = rec["curve"][:curve.shape[1]]
         with np.errstate(divide="ignore", invalid="ignore"):
             rel = np.where(ref != 0, np.abs(curve / ref - 1.0), 0.0)
-        cm = curve.mean(axis=0, keepdims=True)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            own = np.where(cm != 0, np.abs(curve / cm - 1.0), 0.0).max(axis=0)          # this path against itself over the partitions (a term that is off: 0)
         print("   total loss every %d iterations, reference:        %s" % (every, np.array2string(ref[:, 5], precision=1, max_line_width=600)))
         for part, c in zip(PARTITIONS, curve):
             print("   total loss every %d iterations, hip %-19s %s" % (every, (part or "shipped partition") + ":", np.array2string(c[:, 5], precision=1, max_line_width=600)))
         print("   the six terms (rgb, gradient, rigidity, global rigidity, flow, total) at the last logged iteration, reference: %s" % np.array2string(ref[-1], precision=5, max_line_width=300))
         print("   ... hip, mean over the partitions:                                                                        %s" % np.array2string(curve[:, -1].mean(axis=0), precision=5, max_line_width=300))
         print("   distance from the reference, worst term per logged iteration (best partition): %s" % np.array2string(rel.max(axis=2).min(axis=0), precision=3, max_line_width=600))
-        print("   this path against itself over the partitions, worst term per logged iteration:  %s" % np.array2string(own.max(axis=1), precision=3, max_line_width=600))
         # iteration 0: the same batch on a state 8000 chaotic steps old (test_gpu_c1.py: 6 % on this side from one ulp of one weight)
         assert rel[:, 0, 5].min() < 0.10, (curve[:, 0], ref[0])
         assert np.all((ref[:, 3] > 0) == (np.arange(len(ref)) * every <= 5000)) and np.all((curve[:, :, 3] > 0) == (ref[None, :, 3] > 0))   # the switch at 5000, both sides
-        # along the curve: the total and the rgb term (what the PSNR is made of) stay within the spread the three partitions show among
-        # themselves plus 10 %, at every logged iteration including the 5000 without global rigidity
+        # along the curve: the total and the rgb term (what the PSNR is made of) stay within 15 % of the reference's at every logged iteration, the 5000
+        # without global rigidity included (two runs of either side differ by 1-8 % there: profiles/r5_pytest_c2_complete.log)
         for t in (0, 5):
-            lim = 0.10 + 2.0 * own[:, t]
-            assert np.all(rel[:, :, t].min(axis=0) <= lim), (TERMS[t], rel[:, :, t].min(axis=0), lim)
+            assert np.all(rel[:, :, t].min(axis=0) <= 0.15), (TERMS[t], rel[:, :, t].min(axis=0))
         for i in sorted(rec["psnr_at"]):
-            if all(i in r[1] for r in runs):
-                h = np.array([r[1][i] for r in runs])
-                refs = [rec["psnr_at"][i]] + ([arms2[seed][1][i]] if seed in arms2 and i in arms2[seed][1] else [])
-                print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %s dB" % (i, np.array2string(h, precision=4), h.mean(), np.round(refs, 4)))
-                d_mid.append((float(h.mean() - np.mean(refs)), len(refs))); sig.append(h)
-        if complete:
-            h = np.array([r[2] for r in runs])
-            refs = [rec["psnr_end"]] + ([arms2[seed][2]] if seed in arms2 else [])
-            print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %s dB" % (rec["iters"], np.array2string(h, precision=4), h.mean(), np.round(refs, 4)))
-            d_end.append((float(h.mean() - np.mean(refs)), len(refs))); sig.append(h)
-    if not sig:
-        return
-    # one run's standard deviation on this side, pooled over every (seed, evaluation) the partitions were compared at
-    sigma = float(np.sqrt(np.mean([np.var(h, ddof=1) for h in sig])))
-    npart = len(PARTITIONS)
-    # the reference against itself at this size, where a second arm exists (tests/golden/c2_reference_rerun.npz: the same seed at another thread
-    # count, i.e. another summation order inside its GEMMs and nothing else): its run-to-run sigma from the pairs; else assumed equal to this side's
-    sigma_ref, pairs = sigma, []
-    for s2, (pre2, at2, end2, thr2) in arms2.items():
+            h = np.array([r[1][i] for r in runs])
+            refs = [rec["psnr_at"][i]] + ([arms2[seed][1][i]] if seed in arms2 and i in arms2[seed][1] else [])
+            print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %s dB" % (i, np.array2string(h, precision=4), h.mean(), np.round(refs, 4)))
+            d_mid.append(float(h.mean() - np.mean(refs))); sig.append(h)
+        h = np.array([r[2] for r in runs])
+        refs = [rec["psnr_end"]] + ([arms2[seed][2]] if seed in arms2 else [])
+        print("   PSNR after %d iterations: hip %s (mean %.4f) / reference %s dB" % (rec["iters"], np.array2string(h, precision=4), h.mean(), np.round(refs, 4)))
+        d_end.append(float(h.mean() - np.mean(refs))); sig.append(h); narm.append(len(refs))
+    # one run's standard deviation on this side: measured over the partitions when they were run, else the recorded figure of that variant
+    sigma = float(np.sqrt(np.mean([np.var(h, ddof=1) for h in sig]))) if npart > 1 else SIGMA_HIP_RECORDED
+    # the reference against itself at this size: its run-to-run sigma from its own pairs of arms (another thread count, nothing else)
+    pairs = []
+    for s2, (pre2, at2, end2, thr2) in sorted(arms2.items()):
         rec = recs[s2]
         pairs += [end2 - rec["psnr_end"]] + [at2[i] - rec["psnr_at"][i] for i in at2 if i in rec["psnr_at"]]
         print("reference against itself, seed %d (%d vs %d threads): PSNR after the pre-train %.4f / %.4f, after 5000 iterations %s / %s, at the end %.4f / %.4f dB"
               % (s2, thr2, rec.get("threads", -1), pre2, rec["psnr_pre"], [round(v, 4) for v in at2.values()], [round(rec["psnr_at"][i], 4) for i in at2 if i in rec["psnr_at"]], end2, rec["psnr_end"]))
-    if pairs:
-        sigma_ref = max(sigma, float(np.sqrt(np.mean(np.square(pairs)) / 2.0)))
-        print("reference run-to-run sigma from %d paired evaluations: %.3f dB" % (len(pairs), float(np.sqrt(np.mean(np.square(pairs)) / 2.0))))
-    print("sigma of one run on this side (pooled over partitions): %.3f dB, of the reference %.3f dB" % (sigma, sigma_ref))
+    assert len(arms2) >= 4, "the reference's sigma at this size needs its own pairs: >= 4 seeds with a second arm (tests/golden/c2_reference_rerun.npz)"
+    sigma_ref = float(np.sqrt(np.mean(np.square(pairs)) / 2.0))
+    print("reference run-to-run sigma from %d paired evaluations of %d seeds: %.3f dB ; sigma of one run on this side (%s): %.3f dB"
+          % (len(pairs), len(arms2), sigma_ref, "pooled over %d partitions" % npart if npart > 1 else "recorded, profiles/r6_pytest_c2_all_partitions.log", sigma))
+    narm = np.array(narm, np.float64)
     for name, dd in (("after the pre-train", d_pre), ("after 5000 iterations", d_mid), ("at the end", d_end)):
-        if not dd:
-            continue
-        d, arms = np.array([x for x, _ in dd]), np.array([n for _, n in dd], np.float64)
-        se = float(d.std(ddof=1) / np.sqrt(len(d))) if len(d) > 1 else float("nan")
+        d = np.array(dd)
+        se = float(d.std(ddof=1) / np.sqrt(len(d)))
         print("hip - reference %s (a seed with two reference arms: against their mean): per seed %s dB ; mean %+.4f dB, standard error over seeds %.4f dB (n = %d)"
               % (name, np.array2string(d, precision=4), d.mean(), se, len(d)))
         if name == "after the pre-train":
             continue
-        # BASELINE.md's 0.1 dB on top of two standard errors of the difference of the two means, per seed and over the seeds: the reference's sigma from its
-        # own pair of arms where one exists (seed 1 on the field-flow video: 27.35 / 27.51 dB at the end, 27.25 / 27.50 at the switch — 0.15 dB, four times
-        # this path's partition sigma on the translating videos), this path's from its three partitions
-        tol_seed = 0.1 + 2.0 * np.sqrt(sigma_ref ** 2 / arms + sigma ** 2 / npart)
-        tol_mean = 0.1 + 2.0 * np.sqrt(np.mean(sigma_ref ** 2 / arms + sigma ** 2 / npart) / len(d))
-        print("   tolerances: per seed %s dB, on the mean %.3f dB" % (np.round(tol_seed, 3), tol_mean))
+        # per seed: BASELINE.md's 0.1 dB on top of two standard deviations of the difference of one HIP run (mean of npart) and the mean of that seed's reference arms
+        tol_seed = 0.1 + 2.0 * np.sqrt(sigma_ref ** 2 / narm + sigma ** 2 / npart)
+        print("   tolerances: per seed %s dB ; on the mean 0.1 + 2 SE = %.3f dB with SE <= %.3f required" % (np.round(tol_seed, 3), 0.1 + 2.0 * se, SE_MAX))
         assert np.all(np.abs(d) <= tol_seed), (name, d, tol_seed)
-        assert abs(float(d.mean())) <= tol_mean, (name, float(d.mean()), tol_mean)
+        assert len(d) >= 8 and se <= SE_MAX, (name, len(d), se)                        # the comparison resolves what it claims to
+        assert abs(float(d.mean())) <= 0.1 + 2.0 * se, (name, float(d.mean()), se)
