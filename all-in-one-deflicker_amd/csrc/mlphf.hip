@@ -70,6 +70,9 @@ struct HfStream {
   }
   // the five pieces a k-step issues right behind its own publish, for a stage opened elsewhere
   AF_DEV void lead5() { issue1(); issue1(); issue1(); issue1(); issue1(); }
+  // a whole stage at once: the head of a chain has no MFMA shadow to spread the pieces over, and a chunk issued early has landed by its publish
+  // (tools/hfbench.hip: the first two publishes of a task exposed ~2 k ticks of DMA latency each).  BYTES: what the chunk really holds.
+  AF_DEV void issue_bytes(int BYTES) { const int n = (BYTES + 4095) / 4096; while (p_it < n) issue1(); p_it = NI; }
   AF_DEV void start(const void* img, int tid, int wave_) { src = (const char*)img + tid * 16; wave = wave_; stg = 0; begin_stage(); }
   // KEEP: tile stores this wave has issued AFTER the last piece of the chunk being published (vmcnt retires loads and stores in
   // issue order: the counted wait covers every DMA piece and leaves the youngest stores in flight).  Callers that cannot bound the
@@ -318,6 +321,7 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
   using CB = ChunkBytesHf<NS>;
   HfStream cs; cs.smem = smem;
   cs.start(a.wimg, tid, wave);
+  cs.issue_bytes(CB::L0);                            // the layer-0 chunk travels while the input stage computes
   const int nl = a.nl;
   stage_bias(nl, a.bias, smem + AF_BIAS_LDS_HF, tid);
   constexpr int NPE = NS::PEG > 0 ? NS::PEG * 4 : 4;
@@ -382,13 +386,15 @@ AF_DEV void mlp_fwd_body_hf(const FwdArgs& a, int wg, char* smem) {
     }
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
+  auto hook_none = [&](auto) {};
 
   // ---- layer 0 (fp32 block); the chunk behind it is the first fp16 chunk of layer 1
   HF_MARK(1);
   const char* cur = cs.publish(CB::L0);             // its barrier also publishes the bias rows
+  cs.issue_bytes(nl > 2 ? CB::HID : CB::last_bytes(nl));      // the chunk behind layer 0, whole: it lands under the layer-0 block and its pre-pass
   HF_MARK(2);
   init_bias(acc, bias_lds, 0, h);
-  mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_dma);
+  mm_block<8, NS::K0G, 0, 4>(acc, pe, cur + a_off8, hook_none);
   HF_MARK(3);
   pre_out(0, std::false_type{});
   HF_MARK(4);
@@ -493,6 +499,7 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
   using CB = ChunkBytesHf<NS>;
   HfStream cs; cs.smem = smem;
   cs.start(a.wimg, tid, wave);
+  cs.issue_bytes(CB::BLAST);                         // the output layer's chunk travels while the seed gradient is formed
   const int nl = a.nl;
 
   float dzl[4];
@@ -534,12 +541,14 @@ AF_DEV void mlp_bwd_body_hf(const BwdArgs& a, int wg, char* smem) {
   };
   auto hook_dma = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } };
   auto hook_dma_store = [&](auto gi) { if constexpr (decltype(gi)::value < 6) { cs.issue1(); cs.issue1(); } ts.template part<decltype(gi)::value>(in); };
+  auto hook_none = [&](auto) {};
 
   // ---- output layer (fp32 block): K = 8 (one group), only p < OUT non-zero
   HF_MARK(1);
   const char* cur = cs.publish(CB::BLAST);
+  cs.issue_bytes(nl > 2 ? CB::HID : (NS::DX0 ? CB::BL0H : 4096));      // the chunk behind it, whole
   HF_MARK(2);
-  mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_dma);
+  mm_block<8, 1, 0, NS::OUT, true>(acc, dzl, cur + a_off8, hook_none);
   HF_MARK(3);
   pre_mask(nl - 1, std::false_type{});
   HF_MARK(4);

@@ -78,3 +78,33 @@ def test_mlp_modes_agree_at_full_size(two_layer):
     af.close()
     del video
     torch.cuda.empty_cache()
+
+
+def test_f16x3_reports_a_weight_beyond_its_images_range():
+    """mlphf.hip scales the fp16 weight images by a fixed 2^12 (finite for |w| < 16): k_adam raises the handle's range flag at |w| >= 8 and
+    af_train_steps returns AF_ERANGE (include/atlasfit.h) instead of training on with a saturated image; the bf16x6 chains (mode 1) have no such limit
+    and go on from the same state."""
+    import aiod_amd
+    from oracle import atlas_oracle as O
+    import bench
+    v = O.synthetic_video(64, 48, 4, seed=0)
+    af = aiod_amd.AtlasFit(aiod_amd.default_config(64, 48, 4, samples_batch=256))
+    af.upload_video(v.video_frames, v.optical_flows, v.optical_flows_reverse, v.optical_flows_mask, v.optical_flows_reverse_mask)
+    sds = bench.init_state_dicts(3)
+    for net in af.nets:
+        af.load_state_dict(net, sds[net])
+    assert af.arithmetic["mlp_mode"] == 3                                            # the library's default
+    assert np.isfinite(af.train_steps(0, 2, None, seed=1)).all()
+    big = {k: np.array(val, copy=True) for k, val in af.state_dict(aiod_amd.NET_MAPPING1).items()}
+    big["hidden.2.weight"][5, 7] = 9.0
+    af.load_state_dict(aiod_amd.NET_MAPPING1, big)
+    with pytest.raises(aiod_amd.AtlasFitError) as e:
+        af.train_steps(2, 1, None, seed=1)
+    assert e.value.code == -6 and "fp16 weight images" in str(e.value), (e.value.code, str(e.value))
+    af.set_mlp_mode(1)                                                               # the cross-check arithmetic takes the same state
+    af.load_state_dict(aiod_amd.NET_MAPPING1, big)
+    assert np.isfinite(af.train_steps(3, 1, None, seed=1)).all()
+    af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1])           # (the flag is sticky until a call reports it: back in range BEFORE the switch re-emits the fp16 images)
+    af.set_mlp_mode(3)
+    assert np.isfinite(af.train_steps(4, 1, None, seed=1)).all()                     # and mode 3 trains again once the weight is back in range
+    af.close()
