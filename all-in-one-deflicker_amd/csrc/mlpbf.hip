@@ -90,6 +90,9 @@ AF_DEV f32x4 bf_frag_a(uint32_t lane_addr) {
   return v;
 }
 AF_DEV void bf_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the same wait tied to the fragment the slot's first MFMA reads (round 6, found by isa_check.py rule (a) on mlphf.hip): an MFMA has no memory side and no
+// other dependency on a bare wait, so inside its slot hipcc is free to schedule it in front of one
+AF_DEV void bf_lds_wait(f32x4& frag) { asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(frag) :: "memory"); }
 AF_DEV f32x16 bf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -236,7 +239,9 @@ AF_DEV void bf_slot(f32x16 (&acc)[8], const float (&in)[128], BfPipe& pp, f32x4 
                     uint32_t la, uint32_t nla, BfStream& cs, const TileStore& ts) {
   constexpr int sl = S & 1, T = I & 7;
   constexpr bool odd = sl == 1, NEXT_BF = S != 15, stores = NST > 0 && S < 8;
-  if constexpr (I == 0 || I == 8 || I == 24) bf_lds_wait();          // the fragments of this slot group have landed (read >= 4 MFMAs ago)
+  if constexpr (I == 0) bf_lds_wait(pp.fl[0]);                       // the fragments of this slot group have landed (read >= 4 MFMAs ago)
+  if constexpr (I == 8) bf_lds_wait(fm[0]);
+  if constexpr (I == 24) bf_lds_wait(fh[0]);
   // ---- the MFMA
   if constexpr (I < 8) {
     pin_acc(pp.fl[T]);

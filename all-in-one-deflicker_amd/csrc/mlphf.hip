@@ -103,6 +103,9 @@ AF_DEV f32x4 hf_frag_a(uint32_t lane_addr) {      // straight into an accumulato
   return v;
 }
 AF_DEV void hf_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The same wait TIED to the fragment the slot's MFMA reads: an MFMA has no memory side and no other dependency on the wait, so inside its slot hipcc
+// may schedule it in front of a bare wait (it did once the chains' row-exponent stores shifted the schedule: isa_check.py rule (a) refused the build)
+AF_DEV void hf_lds_wait(f32x4& frag) { asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(frag) :: "memory"); }
 AF_DEV f32x16 hf_mfma(const f32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -126,13 +129,16 @@ AF_DEV HfB hf_split_in(const float (&in)[128], int s8, float sc) {
 // The row's scale from the lane's maximum: mx <- max over both lane halves, s = 2^(15 - exponent(mx)) (mx s in [2^14, 2^15)), and
 // the factor that takes the accumulator back: inv = 1 / (s 2^12).  Exponents beyond +-60 are clamped (a row whose largest magnitude
 // is below 2^-45 loses bits it does not have; above 2^75 the chain holds non-finite values anyway and k_adam's flag is up).
-AF_DEV void hf_row_scale(float mx, float& sc, float& inv) {
+// Returns the exponent e of the scale (s = 2^e), or -128 for an all-zero row.
+AF_DEV int hf_row_scale(float mx, float& sc, float& inv) {
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   int e = 15 - __builtin_amdgcn_frexp_expf(mx);
   e = e > 60 ? 60 : (e < -60 ? -60 : e);
-  if (!(mx > 0.f)) e = 0;
+  const bool zero = !(mx > 0.f);
+  if (zero) e = 0;
   sc = __builtin_ldexpf(1.f, e);
   inv = __builtin_ldexpf(1.f, -e - AF_HF_WSHIFT);
+  return zero ? -128 : e;
 }
 // shift the bit "v > 0" (the sign of 0 - v) into a mask word, as one opaque pair: written in C the 128 subtractions of a layer are SLP-packed into
 // v_pk_add_f32 on register pairs and batched ahead of their use (7 spilled registers in the atlas net's training chain)
@@ -178,7 +184,8 @@ AF_DEV void hf_slot(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, f3
                     uint32_t la, uint32_t nla, HfStream& cs, const TileStore& ts, HfFin& fin) {
   constexpr int sl = S & 3, T = I & 7;
   constexpr bool NEXT = S != 15;
-  if constexpr (I == 0 || I == 8) hf_lds_wait();          // the fragments of this slot group have landed (read >= 4 MFMAs ago)
+  if constexpr (I == 0) hf_lds_wait(pp.fl[0]);            // the fragments of this slot group have landed (read >= 4 MFMAs ago)
+  if constexpr (I == 8) hf_lds_wait(fh[0]);
   // ---- the MFMA
   if constexpr (I < 8) {
     pin_acc(pp.fl[T]);
