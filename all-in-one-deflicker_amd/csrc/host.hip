@@ -1225,13 +1225,17 @@ int af_pretrain(af_handle* h, int net, int pretrain_iters, const int64_t* ys, co
       p.half_main = half_main; p.t = (float)((double)f / (F / 2.0) - 1.0);
       p.coords = M.coords; p.x0_tile = M.x0_tile;
       if (af_launch_pre_prep(&p, h->stream)) { rc = h->fail(AF_EHIP, "pre_prep"); break; }
-      // 16-row chains (mlp16.hip): the batch is smaller than one round of the chip, so a step is bound by the latency
-      // of one tile chain — half the rows per wave, half the latency
-      { Timer t(h, T_FWD_1, (double)NB * h->flop_fwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
+      // The batch is smaller than one round of the chip, so a step is bound by the LATENCY of one tile chain.  With the f16x3 arithmetic the 32-row chains
+      // (mlphf.hip: 79 workgroups, a 128-row task in ~45 us at the idle chip's clock) are shorter than the 16-row fp32-MFMA chains built for this case
+      // (mlp16.hip: half the rows per wave, 74 us per direction); the other arithmetics keep those.
+      const bool hf = h->mlp_mode == 3;
+      if (hf) { if ((rc = launch_fwd(h, T_FWD_1, {{net, fwd_args(h, M, M.coords, M.out_buf, NT, true, true), NB}}, true)) != 0) break; }
+      else { Timer t(h, T_FWD_1, (double)NB * h->flop_fwd[net]); const FwdArgs fa = fwd_args(h, M, M.coords, M.out_buf, NT, true, false);
         if (af_launch_fwd16(M.kern, &fa, h->stream)) { rc = h->fail(AF_EHIP, "fwd16"); break; } }
       PreLossArgs l{M.coords, M.out_buf, M.dout, h->loss_part, NB, h->cfg.uv_mapping_scale};
       if (af_launch_pre_loss(&l, h->stream)) { rc = h->fail(AF_EHIP, "pre_loss"); break; }
-      { Timer t(h, T_BWD_2, (double)NB * h->flop_dx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
+      if (hf) { if ((rc = launch_bwd(h, T_BWD_2, {{net, bwd_args(h, M, NT, true), NB}})) != 0) break; }
+      else { Timer t(h, T_BWD_2, (double)NB * h->flop_dx[net]); const BwdArgs ba = bwd_args(h, M, NT, false);
         if (af_launch_bwd16(M.kern, &ba, h->stream)) { rc = h->fail(AF_EHIP, "bwd16"); break; } }
       rc = finish_step(h, sc, h->pre_m, h->pre_v, (long long)s + 1, h->loss_log + s * AF_LOSS_W, (NB + 255) / 256, (double)NB * h->flop_fwd[net], false);
     }
