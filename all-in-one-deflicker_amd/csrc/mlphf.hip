@@ -185,7 +185,7 @@ AF_DEV void hf_slot(f32x16 (&acc)[8], float (&in)[128], float sc, HfPipe& pp, f3
   constexpr int sl = S & 3, T = I & 7;
   constexpr bool NEXT = S != 15;
   if constexpr (I == 0) hf_lds_wait(pp.fl[0]);            // the fragments of this slot group have landed (read >= 4 MFMAs ago)
-  if constexpr (I == 8) hf_lds_wait(fh[0]);
+  if constexpr (I == 8 && !(AF_ABL & 128)) hf_lds_wait(fh[0]);      // (AF_ABL bit 7: timing probe, wrong results — is the W_h read latency exposed here?)
   // ---- the MFMA
   if constexpr (I < 8) {
     pin_acc(pp.fl[T]);
