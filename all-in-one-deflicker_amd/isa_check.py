@@ -1,14 +1,17 @@
 """ISA invariants of the hand-scheduled kernels, asserted on the disassembly of every build (build.py calls check_unit after hipcc).
 
-The chains (mlpbf.hip) and the slotted k_dw_bf<6> stage (dw.hip) rely on instruction ORDER that hipcc does not know about: fragment
+The chains (mlphf.hip, mlpbf.hip) and the slotted k_dw_bf<6> stage (dw.hip) rely on instruction ORDER that hipcc does not know about: fragment
 reads issued by inline asm straight into AGPRs (invisible to the compiler's s_waitcnt insertion), LDS-DMA pieces whose arrival is
 published by a COUNTED `s_waitcnt vmcnt(16)` that assumes exactly the 16 tile stores of a k-step are younger than the last piece,
 MFMAs tied to issue slots.  A later edit or a compiler upgrade that re-orders them corrupts results silently or loses the schedule;
 round 3 met both.  Here the build fails instead:
 
-  mlpbf.o  (a) every `ds_read_b128 a[..]` is followed by an `s_waitcnt` with lgkmcnt(0) before the first v_mfma that reads that AGPR;
-           (b) between the last `global_load_lds` and each `s_waitcnt vmcnt(16)` lie exactly 16 buffer_store_dword and no other
-               vector-memory instruction;
+  mlpbf.o, mlphf.o
+           (a) every `ds_read_b128 a[..]` is retired by an `s_waitcnt` (lgkmcnt(0), or a counted lgkmcnt(N) that leaves it among the retired ones) before
+               the first v_mfma that reads that AGPR.  Round 6: this rule refused a build in which hipcc had moved a slot's MFMA in front of the bare
+               wait at the head of its slot group (an MFMA has no dependency on a wait) — the waits now carry the fragment register as an operand;
+           (b) between the last `global_load_lds` and each counted publish `s_waitcnt vmcnt(K)` (K = 16 in mlpbf.o, 8 in mlphf.o) lie exactly K
+               buffer_store_dword and no other vector-memory instruction;
   dw.o     (c) the main loop of k_dw_bf<6> holds 192 MFMAs (two slotted 8x8 stages), never more than two back to back, two counted
                `s_waitcnt vmcnt(8)` + `s_barrier`, and 16 LDS-DMA pieces each directly behind its m0 write and one wait state;
   every unit: no scratch_ instruction (build.py's remark check, restated on the disassembly);
