@@ -239,8 +239,8 @@ def _copy_params_to_oracle(af, nets, models):
 
 def test_full_size_trajectory_matches_oracle(full):
     """BASELINE configs[1] at its real size, in the regime the loop actually runs in: the mapping net pre-trained on
-    the device (pre_train_mapping, unwrap_utils.py:176-198), that state copied into the CPU oracle, then TEN
-    iterations on the same injected indices straddling the global-rigidity switch (i = 4996..5005,
+    the device (pre_train_mapping, unwrap_utils.py:176-198), that state copied into the CPU oracle, then EIGHT (ten until round 6)
+    iterations on the same injected indices straddling the global-rigidity switch (i = 4996..5003,
     stage1_neural_atlas.py:151-231): every loss term of every iteration within BASELINE.json's 1e-3, end weights close."""
     import aiod_amd
     from oracle import atlas_oracle as O
@@ -262,7 +262,7 @@ def test_full_size_trajectory_matches_oracle(full):
     v64 = O.Video(frames.double(), flows[..., None].double(), flows_rev[..., None].double(), mask[..., None], mask_rev[..., None])
     tr64 = O.SingleAtlasTrainer(cfg, v64, mapping=m64, atlas=a64)
     g = torch.Generator().manual_seed(17)
-    K, first = 10, 4996
+    K, first = 8, 4996                          # (round 6: eight iterations, 4996..5003 — five with the global-rigidity rows, three without; the suite's time budget)
     inds = torch.randint(v.F * v.resx * v.resy, (K, cfg["samples_batch"]), generator=g)
     # Round 6: three split-K partitions of the weight-gradient GEMM from the same start state, as in test_full_size_seg_trajectory_matches_oracle (which
     # holds the measured lottery: the pure fp32-MFMA chains stay inside the bound over all ten iterations on 1 partition of 3).  UNCHANGED tolerances:
@@ -387,8 +387,8 @@ def test_full_size_seg_iteration_matches_oracle():
 
 def test_full_size_seg_trajectory_matches_oracle():
     """BASELINE configs[4] at its real size over CONSECUTIVE Adam steps (the full-size fg/bg evidence was single-step):
-    both mapping nets pre-trained on the device, the state copied into the CPU oracle, then TEN iterations of the four-net packed
-    launch plan on the same injected indices straddling the global-rigidity switch (i = 4996..5005, stage1_neural_atlas_seg.py:
+    both mapping nets pre-trained on the device, the state copied into the CPU oracle, then EIGHT iterations (ten until round 6) of the four-net packed
+    launch plan on the same injected indices straddling the global-rigidity switch (i = 4996..5003, stage1_neural_atlas_seg.py:
     193-315, stop_global_rigidity 5000): all 12 loss terms of every iteration within BASELINE.json's 1e-3, end weights close.
 
     Round 4 (field-flow video): two fp32 trajectories of this loop separate by themselves — Adam moves a weight whose gradient is ~0 by
@@ -428,13 +428,13 @@ def test_full_size_seg_trajectory_matches_oracle():
     tr = O.SegAtlasTrainer(cfg, v, models=models)
     tr64 = O.SegAtlasTrainer(cfg, v64, models=m64)
     g = torch.Generator().manual_seed(29)
-    K, first, N = 10, 4996, cfg["samples_batch"]
+    K, first, N = 8, 4996, cfg["samples_batch"]          # (round 6: eight iterations — the CPU oracle and its fp64 twin are 15 s per iteration on the box)
     inds = torch.randint(F * resx * resy, (K, N), generator=g)
     # Round 6: the HIP side runs on three split-K partitions of the weight-gradient GEMM (another summation order, nothing else: test_gpu_c2.py's
     # PARTITIONS) from the same start state.  Whether ONE run stays inside the bound over all ten iterations is a lottery of round-off for EVERY
     # arithmetic — measured (profiles/r6_chaos_seg_full_size_trajectory.log): the pure fp32-MFMA chains (bit for bit an fmaf chain) pass on 1 of the 3
     # partitions, bf16x6 on 2, f16x3 on 1.  Asserted at UNCHANGED tolerances: every partition for the first five iterations (before the divergence has
-    # grown to 1e-3), at least one partition for all ten, and no partition further from the fp64 twin than 8x torch-fp32's own distance.
+    # grown to 1e-3), at least one partition for all of them, and no partition further from the fp64 twin than 8x torch-fp32's own distance.
     start = {net: af.state_dict(net) for net in nets}
     hips = []
     for part in (None, "306,150,126,129,87", "306,170,145,148,100"):
