@@ -506,7 +506,7 @@ def main():
         af.train_steps(wfirst, W, None, seed=rank, return_losses=False)
     tw = af.timing(reset=True)
     # the dominant KERNEL (by name, all of its launches in a step: k_mlp_fwd_multi = fwd_1 + fwd_2, ...), not the dominant launch
-    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["bwd_1"]
+    dom = max(by_name, key=lambda k: sum(tw[c][0] for c in by_name[k])) if W > 0 else KERNEL_OF_CLASS["dw"]
     dom_classes = by_name[dom]
     # events only around the dominant kernel's launches, and only in every EVENT_EVERY-th timed step: an event costs ~5 us in-stream
     # (the all-launches pass below runs 0.06 ms per step slower than the timed region for its 12 further events), four of them in

