@@ -85,7 +85,10 @@ def _run(seed, rec, partition, upto, v):
     losses, p_at, done = [], {}, 0
     for stop in stops:
         if stop > done:
-            inds = torch.stack([torch.randint(P, (N, 1)).view(-1) for _ in range(stop - done)])
+            # the reference draws torch.randint(P, (N, 1)) once per iteration from the global CPU generator; ONE call for all the iterations of the
+            # segment consumes the same stream element by element (the CPU kernel is serial) and leaves the generator in the same state —
+            # pinned on CPU by tests/test_oracle.py::test_one_randint_call_replays_the_per_iteration_draws — at a tenth of the time
+            inds = torch.randint(P, ((stop - done) * N, 1)).view(stop - done, N)
             losses.append(af.train_steps(done, stop - done, inds.numpy()))
             done = stop
         if stop in rec["psnr_at"]:

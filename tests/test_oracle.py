@@ -227,3 +227,16 @@ def test_complete_schedule_fixtures_describe_the_videos_the_gpu_tests_rebuild():
         assert 5000 in [int(i) for i in g["psnr_at_iter"]]
         assert (g["psnr"] > g["psnr_pre"] + 5.0).all() and (g["psnr"] >= g["psnr_at"][:, 0] - 0.5).all()
         assert (g["curves"][:, -1, 5] < 0.35 * g["curves"][:, 0, 5]).all()
+
+
+def test_one_randint_call_replays_the_per_iteration_draws():
+    """tests/test_gpu_c2.py replays a reference run's index draws (stage1_neural_atlas.py:159: torch.randint(P, (N, 1)) per iteration, global CPU
+    generator) with ONE call per segment of the schedule: the same values in the same order, and the generator left in the same state."""
+    P, N, K = 80 * 768 * 432, 10000, 7
+    torch.manual_seed(11)
+    per_iteration = torch.stack([torch.randint(P, (N, 1)).view(-1) for _ in range(K)])
+    after_a = torch.randint(P, (5,))
+    torch.manual_seed(11)
+    one_call = torch.randint(P, (K * N, 1)).view(K, N)
+    after_b = torch.randint(P, (5,))
+    assert torch.equal(per_iteration, one_call) and torch.equal(after_a, after_b)
