@@ -11,6 +11,7 @@ from /root/reference by `oracle/make_golden.py`, which also writes the fixtures 
 `tests/test_oracle.py` re-checks the restatement against those fixtures on every run.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -335,6 +336,19 @@ def affine_compose(a, b):
     return np.concatenate((a[:, :2] @ b[:, :2], a[:, :2] @ b[:, 2:3] + a[:, 2:3]), axis=1)
 
 
+def _for_each_frame(fn, nframes):
+    """Frames of a synthetic video are independent of each other and write disjoint slices: a few threads (numpy releases the GIL inside
+    its loops) build them side by side — the same operations per frame in the same order, hence the same bits as the plain loop."""
+    workers = min(8, os.cpu_count() or 1, nframes)
+    if workers <= 1:
+        for f in range(nframes):
+            fn(f)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fn, range(nframes)))
+
+
 def synthetic_video(resx, resy, nframes, seed=0, vx=1.5, vy=0.5, flow="constant", flicker=True):
     """Seeded synthetic flickering video with analytic optical flow: a smooth random texture
     translating (vx, vy) px/frame, per-frame gain U(0.8,1.2) and gamma U(0.9,1.1); forward/backward flows are
@@ -358,13 +372,15 @@ def synthetic_video(resx, resy, nframes, seed=0, vx=1.5, vy=0.5, flow="constant"
     gain = rng.uniform(0.8, 1.2, nframes)
     gamma = rng.uniform(0.9, 1.1, nframes)
     frames = np.zeros((resy, resx, 3, nframes), np.float32)
-    for f in range(nframes):
+
+    def one_frame(f):
         xs, ys = xx - f * vx, yy - f * vy
         tex = np.zeros((resy, resx, 3))
         for w in range(nwave):
             tex += amp[w] * np.sin(kx[w] * xs[..., None] + ky[w] * ys[..., None] + ph[w])
         tex = 0.5 + 0.5 * tex / amp.sum(0)
         frames[:, :, :, f] = np.clip(gain[f] * np.clip(tex, 1e-3, 1.0) ** gamma[f], 0.0, 1.0)
+    _for_each_frame(one_frame, nframes)
     flows = np.zeros((resy, resx, 2, nframes, 1), np.float32)
     flows_rev = np.zeros_like(flows)
     mask = np.zeros((resy, resx, nframes, 1), np.float32)
@@ -400,8 +416,16 @@ def _synthetic_video_field(resx, resy, nframes, seed, flicker=True):
     flows_rev = np.zeros_like(flows)
     mask = np.zeros((resy, resx, nframes, 1), np.float32)
     mask_rev = np.zeros_like(mask)
-    inv = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])                 # frame pixel -> texture coordinate, frame 0 = identity
-    for f in range(nframes):
+    invs = [np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])]              # frame pixel -> texture coordinate, frame 0 = identity
+    pairs = []
+    for f in range(nframes - 1):                                       # the chain of transforms is sequential (and costs nothing) ...
+        a = field_affine(mo, f, resx, resy)
+        ai = affine_inverse(a)
+        pairs.append((a, ai))
+        invs.append(affine_compose(invs[-1], ai))
+
+    def one_frame(f):                                                  # ... the per-pixel work of a frame depends on its own transform only
+        inv = invs[f]
         xs = inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]
         ys = inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]
         tex = np.zeros((resy, resx, 3))
@@ -410,15 +434,14 @@ def _synthetic_video_field(resx, resy, nframes, seed, flicker=True):
         tex = 0.5 + 0.5 * tex / amp.sum(0)
         frames[:, :, :, f] = np.clip(gain[f] * np.clip(tex, 1e-3, 1.0) ** gamma[f], 0.0, 1.0)
         if f == nframes - 1:
-            break
-        a = field_affine(mo, f, resx, resy)
-        ai = affine_inverse(a)
+            return
+        a, ai = pairs[f]
         f12, f21 = field_flow_pair(mo, f, a, ai, xx, yy)
         flows[:, :, :, f, 0] = f12
         flows_rev[:, :, :, f + 1, 0] = f21
         mask[:, :, f, 0] = compute_consistency(f12, f21) < 1.0             # unwrap_utils.py:151-159
         mask_rev[:, :, f + 1, 0] = compute_consistency(f21, f12) < 1.0
-        inv = affine_compose(inv, ai)
+    _for_each_frame(one_frame, nframes)
     t = torch.from_numpy
     return Video(t(frames), t(flows), t(flows_rev), t(mask), t(mask_rev))
 
