@@ -34,6 +34,7 @@ SIGMA_HIP_RECORDED = 0.13          # dB: pooled run-to-run sigma of this path ov
 # dB: the largest standard error of the mean paired difference under which "within 0.1 dB" counts as a resolved statement.  One run per seed carries this
 # side's full run-to-run sigma (0.13 dB) next to the reference's (0.1 dB): n = 8 resolves ~0.06 dB; the mean of three partitions per seed ~0.04 dB.
 SE_MAX = 0.04 if os.environ.get("AF_C2_ALL_PARTITIONS") else 0.07
+ITER0_TOL = 0.25
 TERMS = ("rgb", "gradient", "rigidity", "global_rigidity", "flow", "total")
 
 
@@ -142,8 +143,10 @@ def test_configs1_full_schedule_against_the_reference_modules():
         print("   the six terms (rgb, gradient, rigidity, global rigidity, flow, total) at the last logged iteration, reference: %s" % np.array2string(ref[-1], precision=5, max_line_width=300))
         print("   ... hip, mean over the partitions:                                                                        %s" % np.array2string(curve[:, -1].mean(axis=0), precision=5, max_line_width=300))
         print("   distance from the reference, worst term per logged iteration (best partition): %s" % np.array2string(rel.max(axis=2).min(axis=0), precision=3, max_line_width=600))
-        # iteration 0: the same batch on a state 8000 chaotic steps old (test_gpu_c1.py: 6 % on this side from one ulp of one weight)
-        assert rel[:, 0, 5].min() < 0.10, (curve[:, 0], ref[0])
+        # iteration 0: the same batch on a state 8000 chaotic steps old.  The total is dominated by the global-rigidity term of a few rows; where on
+        # its orbit around the pre-train minimum step 8000 falls moves it by up to 15 % between this path's OWN partitions (seed 0: 1041 / 1183 / 1218
+        # against the reference's 1229, profiles/r5_pytest_c2_complete.log; 1390 in the f16x3 arithmetic) — one run is held to 25 %, ITER0_TOL
+        assert rel[:, 0, 5].min() < ITER0_TOL, (curve[:, 0], ref[0])
         assert np.all((ref[:, 3] > 0) == (np.arange(len(ref)) * every <= 5000)) and np.all((curve[:, :, 3] > 0) == (ref[None, :, 3] > 0))   # the switch at 5000, both sides
         # along the curve: the total and the rgb term (what the PSNR is made of) stay within 15 % of the reference's at every logged iteration, the 5000
         # without global rigidity included (two runs of either side differ by 1-8 % there: profiles/r5_pytest_c2_complete.log)
