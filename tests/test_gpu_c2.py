@@ -4,8 +4,8 @@ the global-rigidity rows and 5000 without them (stage1_neural_atlas.py:151-231,2
 
 tests/golden/c2_reference.npz is written by `oracle/make_golden_c1.py --resx 768 --resy 432 --iters 10001 --log-every 250 --psnr-at 5000` in the
 build container (the reference's IMLP / loss functions / pre_train_mapping / torch.optim.Adam; 3-8 CPU-hours per run): per seed the PSNR after
-the pre-train, after 5000 iterations and at the end, and the six loss terms every 250 iterations.  Even seeds run on the translating video, odd
-ones on the video whose flow differs at every pixel of every frame (holed masks).  tests/golden/c2_reference_rerun.npz holds SECOND arms of the
+the pre-train, after 5000 iterations and at the end, and the six loss terms every 250 iterations.  Seeds 0, 2, 5, 7 run on the translating video,
+seeds 1, 4, 6, 8 on the video whose flow differs at every pixel of every frame (holed masks); the record names each seed's video.  tests/golden/c2_reference_rerun.npz holds SECOND arms of the
 same seeds at another thread count (another summation order inside the reference's GEMMs and nothing else): the reference against itself, which
 gives its run-to-run sigma at this size from its own pairs.
 
