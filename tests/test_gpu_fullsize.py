@@ -266,7 +266,7 @@ def test_full_size_trajectory_matches_oracle(full):
     inds = torch.randint(v.F * v.resx * v.resy, (K, cfg["samples_batch"]), generator=g)
     # Round 6: three split-K partitions of the weight-gradient GEMM from the same start state, as in test_full_size_seg_trajectory_matches_oracle (which
     # holds the measured lottery: the pure fp32-MFMA chains stay inside the bound over all ten iterations on 1 partition of 3).  UNCHANGED tolerances:
-    # every partition for the first five iterations, at least one for all ten, none further from the fp64 twin than 8x torch-fp32's own distance.
+    # every partition for the first five iterations, at least one for all of them, none further from the fp64 twin than 8x torch-fp32's own distance.
     start = {net: af.state_dict(net) for net in nets}
     hips = []
     for part in (None, "306,150,126,129,87", "306,170,145,148,100"):
@@ -428,7 +428,7 @@ def test_full_size_seg_trajectory_matches_oracle():
     tr = O.SegAtlasTrainer(cfg, v, models=models)
     tr64 = O.SegAtlasTrainer(cfg, v64, models=m64)
     g = torch.Generator().manual_seed(29)
-    K, first, N = 8, 4996, cfg["samples_batch"]          # (round 6: eight iterations — the CPU oracle and its fp64 twin are 15 s per iteration on the box)
+    K, first, N = 7, 4996, cfg["samples_batch"]          # (round 6: seven iterations, 4996..5002 — the CPU oracle and its fp64 twin are 15-20 s per iteration on the box)
     inds = torch.randint(F * resx * resy, (K, N), generator=g)
     # Round 6: the HIP side runs on three split-K partitions of the weight-gradient GEMM (another summation order, nothing else: test_gpu_c2.py's
     # PARTITIONS) from the same start state.  Whether ONE run stays inside the bound over all ten iterations is a lottery of round-off for EVERY

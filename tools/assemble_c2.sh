@@ -13,3 +13,6 @@ for f in ("c2_reference", "c2_reference_rerun"):
     d = np.load("tests/golden/%s.npz" % f)
     print(f, "seeds", d["seeds"], "threads", d["threads_per_seed"], "flow", d["flow_kind"], "PSNR end", np.round(d["psnr"], 3), "at 5000", np.round(d["psnr_at"][:, 0], 3), "cpu h", np.round(d["cpu_seconds"].sum(1) / 3600, 1))
 PY
+# ... and the second arm of seed 6 (eight threads), run after the first comparison showed that seed 0.5 dB apart at the switch:
+#   python oracle/make_golden_c1.py --resx 768 --resy 432 --iters 10001 --log-every 250 --psnr-at 5000 --seeds 6 --flow field --threads 8 --out .c2runs/c2_s6_arm2_t8.npz
+#   python oracle/make_golden_c1.py --merge tests/golden/c2_reference_rerun.npz .c2runs/c2_s6_arm2_t8.npz --out tests/golden/c2_reference_rerun.npz
