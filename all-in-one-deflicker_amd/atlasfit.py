@@ -27,6 +27,9 @@ ABI_SYMBOLS = [
 ]
 
 
+AF_ERANGE = -6      # include/atlasfit.h
+
+
 class AtlasFitError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("atlasfit error %d: %s" % (code, msg))
@@ -414,7 +417,7 @@ class AtlasFit:
         if ys is not None:
             ys = np.ascontiguousarray(ys, np.int64); xs = np.ascontiguousarray(xs, np.int64)
             assert ys.size == steps * self.cfg.pretrain_batch == xs.size
-        self._chk(self.lib.af_pretrain(self.h, net, int(pretrain_iters), _ptr(ys), _ptr(xs), int(seed), _ptr(losses)))
+        self._chk(self._range_fallback(self.lib.af_pretrain(self.h, net, int(pretrain_iters), _ptr(ys), _ptr(xs), int(seed), _ptr(losses)), "af_pretrain"))
         return losses
 
     # ---- the loop body (stage1_neural_atlas.py:151-231)
@@ -423,8 +426,24 @@ class AtlasFit:
         if inds is not None:
             inds = np.ascontiguousarray(inds, np.int64)
             assert inds.size == n_iters * self.N, (inds.shape, n_iters, self.N)
-        self._chk(self.lib.af_train_steps(self.h, int(first_iter), int(n_iters), _ptr(inds), int(seed), _ptr(losses)))
+        self._chk(self._range_fallback(self.lib.af_train_steps(self.h, int(first_iter), int(n_iters), _ptr(inds), int(seed), _ptr(losses)), "af_train_steps"))
         return losses
+
+    range_fallback = False
+
+    def _range_fallback(self, rc, what):
+        """AF_ERANGE (include/atlasfit.h): in the f16x3 arithmetic k_adam saw a hidden-layer weight at |w| >= 8 — half of what the fp16 weight images
+        hold.  The steps of the call that reports it are complete and valid (the images are finite below 16 and Adam moves a weight by <= lr per step;
+        the losses are already written), so a caller that must not stop — the stage-1 CLIs set `range_fallback = True` — goes on from the same state
+        on the bf16x6 chains, which have no range limit; said on stderr and recorded in `self.arithmetic` (-> config.json).  Off by default: the
+        library's own behaviour is the error."""
+        if rc != AF_ERANGE or not self.range_fallback:
+            return rc
+        msg = self.lib.af_last_error(self.h).decode()
+        self.set_mlp_mode(1)
+        self.arithmetic.setdefault("overrides", []).append("range fallback after %s: mlp_mode 3 -> 1" % what)
+        sys.stderr.write("[atlasfit] %s -- continuing from the same state on the bf16x6 chains (af_set_mlp_mode(h, 1))\n" % msg)
+        return 0
 
     # ---- evaluate_model_single core (evaluate.py:640-743)
     def render_frame(self, f):

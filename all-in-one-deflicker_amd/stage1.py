@@ -394,11 +394,13 @@ def main(config, args, two_layer=False):
     dev_ord = getattr(args, "device_ordinal", 0)
     F = count_input_frames(config["maximum_number_of_frames"], data_folder)
     af = A.AtlasFit(A.default_config(resx, resy, F, config, two_layer=two_layer), device=dev_ord)
+    af.range_fallback = True      # a weight beyond the fp16 images' range (AF_ERANGE) must not stop a run: go on from the same state on the bf16x6 chains
     # the arithmetic of this run next to its configuration (include/atlasfit.h af_set_mlp_mode / af_set_dw_mode; AF_EXPERIMENT overrides named)
     with open(results_folder / "config.json", "w") as f:
         json.dump(dict(config, atlasfit_arithmetic=af.arithmetic), f, indent=4)
     if af.arithmetic["overrides"]:
         print("arithmetic overrides in force:", af.arithmetic)
+    arithmetic_at_start = dict(af.arithmetic)
     # Random draws: the reference uses torch's process-global RNG.  With --seed (an extension) every draw of this call comes
     # from its own torch.Generator, so concurrent videos in one process (launch_videos.py --concurrent) stay reproducible
     # and independent; without it the global RNG is used like the reference does.
@@ -479,6 +481,9 @@ def main(config, args, two_layer=False):
         i = stop + 1
         if stop % evaluate_every == 0 and stop > start_iteration:
             last_psnr = evaluate_model_single(af, video_frames, results_folder, stop)
+    if af.arithmetic["mlp_mode"] != arithmetic_at_start["mlp_mode"]:      # the range fallback switched the chains' arithmetic on the way: the record says so
+        with open(results_folder / "config.json", "w") as f:
+            json.dump(dict(config, atlasfit_arithmetic=af.arithmetic), f, indent=4)
     af.close()
     mark("loop + evaluation")
     if os.environ.get("AF_CLI_TIMING"):      # wall clock per stage of this process, for tools/cli_end_to_end.py

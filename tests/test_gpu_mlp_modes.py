@@ -107,4 +107,12 @@ def test_f16x3_reports_a_weight_beyond_its_images_range():
     af.load_state_dict(aiod_amd.NET_MAPPING1, sds[aiod_amd.NET_MAPPING1])           # (the flag is sticky until a call reports it: back in range BEFORE the switch re-emits the fp16 images)
     af.set_mlp_mode(3)
     assert np.isfinite(af.train_steps(4, 1, None, seed=1)).all()                     # and mode 3 trains again once the weight is back in range
+    # what the stage-1 CLIs do (AtlasFit.range_fallback): the steps of the reporting call are complete and valid (the images are finite below 16), so the
+    # run goes on from the same state on the bf16x6 chains instead of stopping, and says so
+    af.range_fallback = True
+    af.load_state_dict(aiod_amd.NET_MAPPING1, big)
+    l3 = af.train_steps(5, 2, None, seed=1)                                          # reports AF_ERANGE inside, returns the losses of both steps
+    assert np.isfinite(l3).all() and af.arithmetic["mlp_mode"] == 1 and any("range fallback" in o for o in af.arithmetic["overrides"]), af.arithmetic
+    assert np.isfinite(af.get_params_flat(aiod_amd.NET_MAPPING1)).all()
+    assert np.isfinite(af.train_steps(7, 2, None, seed=1)).all() and af.arithmetic["mlp_mode"] == 1     # ... and the following calls run in mode 1 without a report
     af.close()
